@@ -1,0 +1,209 @@
+/*
+ * evcharge.h — C-ABI of the MI355X-native batched EV-charging step() engine.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json: the body of
+ * SustainGym's EVChargingEnv.step()/reset() (reference: sustaingym/envs/evcharging/env.py)
+ * over a batch of N independent environment instances, executed by hand-written gfx950
+ * HIP kernels.  The reference has no FFI boundary of its own (it is pure Python calling
+ * acnportal + cvxpy); each entry point below therefore cites the reference *Python*
+ * interface it replaces, and INTEGRATION.md shows the ctypes stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions, no callbacks; every function returns 0 on success or a
+ *     negative EVC_E* code; evc_last_error() returns a thread-local message.
+ *   - the engine owns all persistent simulator state (device memory) behind an opaque
+ *     handle; the caller owns every buffer it passes in.
+ *   - "_dev" pointers are device (HBM) addresses valid on the engine's device; all other
+ *     pointers are host addresses.  All GPU work is ordered on the engine's stream
+ *     (evc_set_stream); calls taking only device pointers are asynchronous.
+ *   - one host thread per handle at a time.
+ *   - there is NO CPU execution path in this library: without a visible gfx950 device
+ *     evc_create fails with EVC_ENODEV.
+ *
+ * Data layout
+ *   observation row (float32[F], F = 2n + k + 2), key order = gymnasium.spaces.flatten of
+ *   the reference's Dict space (keys sorted):  env.py:143-150, multiagent_env.py:88,115
+ *       [0,n)        demands          (kWh)
+ *       [n,2n)       est_departures   (periods)
+ *       [2n,2n+k)    forecasted_moer
+ *       [2n+k]       prev_moer
+ *       [2n+k+1]     timestep         (t/288)
+ */
+#ifndef EVCHARGE_H
+#define EVCHARGE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVC_ABI_VERSION 1
+
+#define EVC_MAX_STATIONS     64   /* one gfx950 wavefront per environment            */
+#define EVC_MAX_CONSTRAINTS  32   /* rows of ChargingNetwork.constraint_matrix       */
+#define EVC_MAX_GROUPS       16   /* distinct (column, phase) classes of stations    */
+#define EVC_MOER_ROWS        289  /* MOERLoader.retrieve -> [289,37]                 */
+#define EVC_MOER_COLS        37
+#define EVC_EPISODE_STEPS    288  /* env.py:124 max_timestep                         */
+#define EVC_MAX_SESSIONS     256  /* per episode (real traces <= 81, GMM <= 84)      */
+
+/* EVSE kinds (env.py:371-378; acnportal AeroVironment / ClipperCreek FiniteRatesEVSE) */
+#define EVC_EVSE_AV 0   /* allowable pilots {0} U {6,7,...,32} A */
+#define EVC_EVSE_CC 1   /* allowable pilots {0,8,16,24,32} A     */
+
+/* evc_create flags */
+#define EVC_FLAG_PROJECT_ACTION  (1u << 0)  /* env.py:118 project_action_in_env (default True) */
+#define EVC_FLAG_AUTORESET       (1u << 1)  /* gymnasium 0.28 VectorEnv autoreset semantics     */
+
+/* action encodings for evc_step */
+#define EVC_ACTION_F32       0   /* float32[N][n] in [0,1]            (env.py:171-172)          */
+#define EVC_ACTION_DISCRETE  1   /* int64[N][n] in {0..bins-1}        (wrappers.py:43-45)       */
+
+/* per-environment status bits (replace the reference's exceptions / pdb) */
+#define EVC_STATUS_OCCUPIED     (1u << 0)  /* plug-in into an occupied EVSE (acnportal StationOccupiedError); session skipped */
+#define EVC_STATUS_PROJ_NOCONV  (1u << 1)  /* projection did not reach the KKT tolerance     */
+#define EVC_STATUS_STEP_AFTER_DONE (1u << 2) /* step() on a finished episode without autoreset; step ignored */
+#define EVC_STATUS_ACTION_CLAMPED (1u << 3)  /* action outside [0,1] (or NaN) was clamped       */
+
+/* error codes */
+#define EVC_OK        0
+#define EVC_EINVAL   -1
+#define EVC_ENODEV   -2
+#define EVC_ENOMEM   -3
+#define EVC_EHIP     -4
+#define EVC_ESTATE   -5
+
+typedef struct evc_engine evc_engine;
+
+/* Charging-network descriptor = the fields of acnportal's ChargingNetwork the reference
+ * reads: cn.station_ids order (env.py:133-134), cn.constraint_matrix / cn._phase_angles /
+ * cn.magnitudes (env.py:485-493, 450-451), cn.min_pilot_signals (env.py:373). */
+typedef struct evc_network_desc {
+    int32_t        n_stations;          /* n <= EVC_MAX_STATIONS                       */
+    int32_t        n_constraints;       /* m <= EVC_MAX_CONSTRAINTS                    */
+    const double*  constraint_matrix;   /* [m][n] row-major, real                      */
+    const double*  phase_angles_deg;    /* [n]                                         */
+    const double*  magnitudes;          /* [m] amps                                    */
+    const uint8_t* evse_kind;           /* [n] EVC_EVSE_*                              */
+} evc_network_desc;
+
+/* One charging session of an episode (one acns.PluginEvent + EV, event_generation.py:167-191).
+ * Timestamps are 5-minute period indices in [0,288).  Sessions of an episode are stored
+ * sorted by arrival (stable). */
+typedef struct evc_session {
+    int16_t arrival;
+    int16_t departure;
+    int16_t est_departure;
+    int16_t station;                    /* index into station_ids                      */
+} evc_session;
+
+/* Device output buffers of one step (any pointer except obs/reward/terminated may be NULL). */
+typedef struct evc_step_out {
+    float*   obs;          /* [N][F]   observation AFTER the step (after autoreset: first obs of next episode) */
+    double*  reward;       /* [N]      env.py:457                                                  */
+    uint8_t* terminated;   /* [N]      env.py:283 (event queue empty)                              */
+    double*  breakdown;    /* [N][3]   cumulative profit, carbon_cost, excess_charge (env.py:460-462) */
+    float*   final_obs;    /* [N][F]   terminal observation, written only for terminated rows      */
+    double*  pilots;       /* [N][n]   pilot signals sent to the simulator (A), debug/parity       */
+    double*  rates;        /* [N][n]   actual charging rates (A) = simulator.charging_rates[:,t-1] */
+    double*  projected;    /* [N][n]   projected normalised action (env.py:220), debug/parity      */
+} evc_step_out;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+
+/* Replaces EVChargingEnv.__init__ (env.py:116-176) for a batch of num_envs instances.
+ * bank_slots   = number of episode slots resident in HBM (>= 1)
+ * max_sessions = per-slot session capacity (<= EVC_MAX_SESSIONS)
+ * moer_days    = number of [289][37] MOER day matrices resident in HBM */
+int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t moer_forecast_steps,
+               uint32_t flags, int32_t device, int32_t bank_slots, int32_t max_sessions,
+               int32_t moer_days, evc_engine** out);
+
+/* Replaces EVChargingEnv.close (env.py:466-470). */
+void evc_destroy(evc_engine* e);
+
+const char* evc_last_error(void);
+int evc_abi_version(void);
+
+/* Orders all subsequent engine work on `hip_stream` (a hipStream_t; NULL = default). */
+int evc_set_stream(evc_engine* e, void* hip_stream);
+int evc_synchronize(evc_engine* e);
+
+/* Geometry queries. */
+int evc_obs_dim(const evc_engine* e);        /* F = 2n + k + 2 */
+int evc_num_envs(const evc_engine* e);
+int evc_num_stations(const evc_engine* e);
+int evc_num_groups(const evc_engine* e);
+
+/* ---- episode data (reset-time inputs) --------------------------------------------- */
+
+/* Uploads `num_days` MOER matrices (host float64 [num_days][289][37], the return value of
+ * AbstractTraceGenerator.get_moer, event_generation.py:209-218) into day slots
+ * [first_day, first_day+num_days). */
+int evc_upload_moer(evc_engine* e, int32_t first_day, int32_t num_days, const double* moer);
+
+/* Uploads `count` episodes into bank slots [first_slot, first_slot+count).  Replaces
+ * AbstractTraceGenerator.get_event_queue (event_generation.py:149-207):
+ *   n_sessions[count]; sessions[count][stride]; requested_kwh[count][stride] (already
+ *   capped, event_generation.py:169-170); moer_day[count] = MOER day slot of the episode. */
+int evc_upload_episodes(evc_engine* e, int32_t first_slot, int32_t count, int32_t stride,
+                        const int32_t* n_sessions, const evc_session* sessions,
+                        const double* requested_kwh, const int32_t* moer_day);
+
+/* Autoreset walks the bank: next_slot = (slot + stride) mod bank_slots. */
+int evc_set_autoreset_stride(evc_engine* e, int32_t stride);
+
+/* ---- hot path ---------------------------------------------------------------------- */
+
+/* Replaces EVChargingEnv.reset (env.py:293-338) for `count` environments.
+ * env_ids (host, NULL = all envs 0..count-1), slots (host, bank slot per env, NULL = env id
+ * mod bank_slots).  Writes the reset observation rows into obs_dev ([N][F], may be NULL). */
+int evc_reset(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_t* slots,
+              float* obs_dev);
+
+/* Replaces EVChargingEnv.step (env.py:229-291) incl. _to_schedule / _project_action /
+ * acnsim.Simulator.step / _get_observation / _get_reward, for all N environments.
+ * actions_dev: device [N][n]; action_kind EVC_ACTION_*; bins used for DISCRETE. */
+int evc_step(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
+             const evc_step_out* out);
+
+/* Host-buffer convenience variants (synchronous; staged through pinned memory).  Any
+ * output pointer may be NULL. */
+int evc_reset_host(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_t* slots,
+                   float* obs_host);
+int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, int32_t bins,
+                  const evc_step_out* out_host);
+
+/* ---- state access (checkpoint / metrics / tests) ----------------------------------- */
+
+/* Per-env int32 scalars, host [N][8]: t, cursor, slot, moer_day, n_sessions, next_arrival,
+ * status, episodes_done. */
+int evc_get_env_scalars(evc_engine* e, int32_t* out_host);
+/* Per-station state, host: remaining_kwh [N][n] float64; departure/est_departure [N][n]
+ * int16 (departure == -1: EVSE empty). */
+int evc_get_station_state(evc_engine* e, double* remaining_kwh, int16_t* departure,
+                          int16_t* est_departure);
+int evc_set_station_state(evc_engine* e, const double* remaining_kwh, const int16_t* departure,
+                          const int16_t* est_departure);
+int evc_set_env_scalars(evc_engine* e, const int32_t* in_host);
+int evc_get_breakdown(evc_engine* e, double* out_host /* [N][3] */);
+int evc_set_breakdown(evc_engine* e, const double* in_host);
+int evc_clear_status(evc_engine* e);
+
+/* Device-side reduction of the metrics the multi-GPU all-gather carries:
+ * out_host[8] = sum profit, sum carbon_cost, sum excess_charge (of running episodes),
+ * env-steps executed since create, episodes finished since create, envs with non-zero
+ * status, 0, 0. */
+int evc_read_metrics(evc_engine* e, double* out_host);
+
+/* Duration (ms) of the most recent evc_step's kernels measured with HIP events on the
+ * engine's stream (enabled by evc_enable_timing(e,1)); used by bench.py's roofline leg. */
+int evc_enable_timing(evc_engine* e, int32_t on);
+int evc_last_step_ms(evc_engine* e, float* ms_main, float* ms_slow);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVCHARGE_H */

@@ -1,0 +1,238 @@
+"""ctypes binding of the CPU ORACLE (test infrastructure — NOT product code).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  ``sustaingym_amd`` never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libevc_oracle.so')
+
+MAX_STATIONS = 64
+MOER_ROWS, MOER_COLS = 289, 37
+
+SESSION_DTYPE = np.dtype([('arrival', '<i2'), ('departure', '<i2'),
+                          ('est_departure', '<i2'), ('station', '<i2')])
+
+
+class StepResult(C.Structure):
+    _fields_ = [('reward', C.c_double), ('terminated', C.c_int),
+                ('breakdown', C.c_double * 3),
+                ('pilots', C.c_double * MAX_STATIONS),
+                ('rates', C.c_double * MAX_STATIONS),
+                ('projected', C.c_double * MAX_STATIONS),
+                ('status', C.c_uint32)]
+
+
+def build(force: bool = False) -> str:
+    """Compiles the oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in
+            ('evc_oracle.c', 'evc_oracle_proj.c', 'evc_oracle.h', 'evc_oracle_priv.h')]
+    stale = (not os.path.exists(_LIB_PATH) or
+             any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs))
+    if force or stale:
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'libevc_oracle.so'],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp, i32, dp, fp = C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_float)
+        L.orc_net_create.restype = vp
+        L.orc_net_create.argtypes = [i32, i32, vp, vp, vp, vp]
+        L.orc_net_destroy.argtypes = [vp]
+        L.orc_env_create.restype = vp
+        L.orc_env_create.argtypes = [vp, i32, i32]
+        L.orc_env_destroy.argtypes = [vp]
+        L.orc_env_reset.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.orc_env_step.argtypes = [vp, vp, vp, C.POINTER(StepResult)]
+        L.orc_env_step_discrete.argtypes = [vp, vp, i32, vp, C.POINTER(StepResult)]
+        L.orc_env_t.argtypes = [vp]
+        L.orc_env_t.restype = i32
+        L.orc_env_station_state.argtypes = [vp, vp, vp, vp]
+        L.orc_max_profit.restype = C.c_double
+        L.orc_max_profit.argtypes = [i32, vp, vp]
+        L.orc_project_action.restype = i32
+        L.orc_project_action.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_batch_create.restype = vp
+        L.orc_batch_create.argtypes = [vp, i32, i32, i32]
+        L.orc_batch_destroy.argtypes = [vp]
+        L.orc_batch_set_bank.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, vp]
+        L.orc_batch_reset.argtypes = [vp, vp, vp]
+        L.orc_batch_step.argtypes = [vp, vp, vp, i32, i32, i32, i32] + [vp] * 9
+        L.orc_max_threads.restype = i32
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleNetwork:
+    """Wraps orc_net; built from a ``sustaingym_amd.network.ChargingNetwork``-like object."""
+
+    def __init__(self, net):
+        self.n = int(net.constraint_matrix.shape[1])
+        self.m = int(net.constraint_matrix.shape[0])
+        self._A = np.ascontiguousarray(net.constraint_matrix, dtype=np.float64)
+        self._ph = np.ascontiguousarray(net.phase_angles, dtype=np.float64)
+        self._mag = np.ascontiguousarray(net.magnitudes, dtype=np.float64)
+        self._kind = np.ascontiguousarray(net.evse_kind, dtype=np.uint8)
+        self.handle = lib().orc_net_create(self.n, self.m, _p(self._A), _p(self._ph),
+                                           _p(self._mag), _p(self._kind))
+        if not self.handle:
+            raise RuntimeError('orc_net_create failed')
+
+    def __del__(self):
+        if getattr(self, 'handle', None) and _lib is not None:
+            _lib.orc_net_destroy(self.handle)
+            self.handle = None
+
+    def project(self, action, demands):
+        """env.py:200-221.  Returns (x[n] float64, rc, kkt[4])."""
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        d = np.ascontiguousarray(demands, dtype=np.float32)
+        x = np.empty(self.n, dtype=np.float64)
+        kkt = np.empty(4, dtype=np.float64)
+        rc = lib().orc_project_action(self.handle, _p(a), _p(d), _p(x), _p(kkt))
+        return x, rc, kkt
+
+
+def pack_sessions(arrival, departure, est_departure, station) -> np.ndarray:
+    s = np.empty(len(arrival), dtype=SESSION_DTYPE)
+    s['arrival'], s['departure'] = arrival, departure
+    s['est_departure'], s['station'] = est_departure, station
+    return s
+
+
+class OracleEnv:
+    """One scalar environment (EVChargingEnv restatement)."""
+
+    def __init__(self, onet: OracleNetwork, moer_forecast_steps: int = 36, project: bool = True):
+        self.onet = onet
+        self.n, self.k = onet.n, moer_forecast_steps
+        self.F = 2 * self.n + self.k + 2
+        self.handle = lib().orc_env_create(onet.handle, moer_forecast_steps, int(project))
+        if not self.handle:
+            raise RuntimeError('orc_env_create failed')
+        self._obs = np.zeros(self.F, dtype=np.float32)
+
+    def __del__(self):
+        if getattr(self, 'handle', None) and _lib is not None:
+            _lib.orc_env_destroy(self.handle)
+            self.handle = None
+
+    def reset(self, sessions: np.ndarray, requested: np.ndarray, moer: np.ndarray) -> np.ndarray:
+        sessions = np.ascontiguousarray(sessions, dtype=SESSION_DTYPE)
+        requested = np.ascontiguousarray(requested, dtype=np.float64)
+        moer = np.ascontiguousarray(moer, dtype=np.float64)
+        assert moer.shape == (MOER_ROWS, MOER_COLS)
+        lib().orc_env_reset(self.handle, len(sessions), _p(sessions), _p(requested), _p(moer),
+                            _p(self._obs))
+        return self._obs.copy()
+
+    def step(self, action):
+        res = StepResult()
+        action = np.asarray(action)
+        if np.issubdtype(action.dtype, np.integer):
+            raise TypeError('use step_discrete for integer actions')
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        lib().orc_env_step(self.handle, _p(a), _p(self._obs), C.byref(res))
+        return self._obs.copy(), res
+
+    def step_discrete(self, action, bins: int = 5):
+        res = StepResult()
+        a = np.ascontiguousarray(action, dtype=np.int64)
+        lib().orc_env_step_discrete(self.handle, _p(a), bins, _p(self._obs), C.byref(res))
+        return self._obs.copy(), res
+
+    @property
+    def t(self) -> int:
+        return lib().orc_env_t(self.handle)
+
+    def station_state(self):
+        rem = np.empty(self.n, dtype=np.float64)
+        dep = np.empty(self.n, dtype=np.int16)
+        est = np.empty(self.n, dtype=np.int16)
+        lib().orc_env_station_state(self.handle, _p(rem), _p(dep), _p(est))
+        return rem, dep, est
+
+
+def max_profit(sessions: np.ndarray, requested: np.ndarray) -> float:
+    sessions = np.ascontiguousarray(sessions, dtype=SESSION_DTYPE)
+    requested = np.ascontiguousarray(requested, dtype=np.float64)
+    return lib().orc_max_profit(len(sessions), _p(sessions), _p(requested))
+
+
+class OracleBatch:
+    """N scalar environments stepped in a C loop (OpenMP over environments)."""
+
+    def __init__(self, onet: OracleNetwork, num_envs: int, moer_forecast_steps: int = 36,
+                 project: bool = True):
+        self.onet, self.N, self.n, self.k = onet, num_envs, onet.n, moer_forecast_steps
+        self.F = 2 * self.n + self.k + 2
+        self.handle = lib().orc_batch_create(onet.handle, num_envs, moer_forecast_steps, int(project))
+        self.bank_slots = 0
+        self.stride = 1
+
+    def __del__(self):
+        if getattr(self, 'handle', None) and _lib is not None:
+            _lib.orc_batch_destroy(self.handle)
+            self.handle = None
+
+    def set_bank(self, n_sessions, sessions, requested, moer_day, moer, autoreset_stride=1):
+        n_sessions = np.ascontiguousarray(n_sessions, dtype=np.int32)
+        sessions = np.ascontiguousarray(sessions, dtype=SESSION_DTYPE)
+        requested = np.ascontiguousarray(requested, dtype=np.float64)
+        moer_day = np.ascontiguousarray(moer_day, dtype=np.int32)
+        moer = np.ascontiguousarray(moer, dtype=np.float64)
+        P, stride = sessions.shape
+        assert requested.shape == (P, stride) and moer.shape[1:] == (MOER_ROWS, MOER_COLS)
+        self.bank_slots, self.stride = P, autoreset_stride
+        lib().orc_batch_set_bank(self.handle, P, stride, _p(n_sessions), _p(sessions),
+                                 _p(requested), _p(moer_day), moer.shape[0], _p(moer))
+
+    def reset(self, slots=None) -> np.ndarray:
+        obs = np.zeros((self.N, self.F), dtype=np.float32)
+        s = None if slots is None else np.ascontiguousarray(slots, dtype=np.int32)
+        lib().orc_batch_reset(self.handle, _p(s), _p(obs))
+        return obs
+
+    def step(self, actions, bins: int = 0, autoreset: bool = False, threads: int = 0,
+             debug: bool = True):
+        N, n, F = self.N, self.n, self.F
+        out = {
+            'obs': np.zeros((N, F), np.float32), 'reward': np.zeros(N, np.float64),
+            'terminated': np.zeros(N, np.uint8), 'breakdown': np.zeros((N, 3), np.float64),
+            'final_obs': np.zeros((N, F), np.float32), 'status': np.zeros(N, np.uint32),
+        }
+        if debug:
+            out.update(pilots=np.zeros((N, n)), rates=np.zeros((N, n)), projected=np.zeros((N, n)))
+        actions = np.asarray(actions)
+        if bins > 0:
+            disc, cont = np.ascontiguousarray(actions, dtype=np.int64), None
+        else:
+            disc, cont = None, np.ascontiguousarray(actions, dtype=np.float32)
+        lib().orc_batch_step(self.handle, _p(cont), _p(disc), bins, int(autoreset), self.stride,
+                             threads, _p(out['obs']), _p(out['reward']), _p(out['terminated']),
+                             _p(out['breakdown']), _p(out['final_obs']), _p(out.get('pilots')),
+                             _p(out.get('rates')), _p(out.get('projected')), _p(out['status']))
+        return out
+
+
+def max_threads() -> int:
+    return lib().orc_max_threads()
