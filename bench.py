@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py — env-steps/sec of the batched 54-station EVChargingEnv step() on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
+driver launches one rank per GPU with torch.distributed.run.  A "step" is one pass of the hot
+path (EVChargingEnv.step: projection -> pilots -> ACN-Sim charge/event pass -> observation ->
+reward) over one batch of environments with the actions already resident in HBM.  Environments
+are independent, so they shard over ranks with no data-path collective (weak scaling: fixed
+envs per GPU); only the final metrics are all-gathered.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per env-step, Caltech n=54, k=36
+#   read action 4n = 216; read+write station state {remaining f64, dep i16, est i16} 12n*2 = 1296;
+#   event cursor + next event ~32; MOER row (k+1)*4 = 148; write obs (2n+k+2)*4 = 584;
+#   write reward/done/breakdown 8+1+24 = 33   => 2309 B
+def algorithmic_bytes_per_env_step(n: int, k: int) -> int:
+    return 4 * n + 12 * n * 2 + 32 + (k + 1) * 4 + (2 * n + k + 2) * 4 + 33
+
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec peak
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=576)
+    p.add_argument('--warmup', type=int, default=288)
+    p.add_argument('--envs-per-gpu', type=int, default=65536)
+    p.add_argument('--site', default='caltech', choices=['caltech', 'jpl'])
+    p.add_argument('--no-project', action='store_true', help='project_action_in_env=False')
+    p.add_argument('--bank', type=int, default=8192, help='distinct synthetic episodes resident in HBM')
+    p.add_argument('--ring', type=int, default=8, help='distinct action batches resident in HBM')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-envs', type=int, default=2048)
+    p.add_argument('--cpu-steps', type=int, default=96)
+    p.add_argument('--kernel-timing-steps', type=int, default=64)
+    return p.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from sustaingym_amd.engine import StepEngine
+    from sustaingym_amd.network import site_str_to_site
+    from sustaingym_amd.synthetic import synthetic_episodes, synthetic_moer
+
+    net = site_str_to_site(args.site)
+    n, k = net.num_stations, 36
+    N = args.envs_per_gpu
+    project = not args.no_project
+    P = min(args.bank, max(N, 1))
+    moer_days = 32
+    ns, sess, req, day = synthetic_episodes(P, n, seed=1000 + rank, stride=64, moer_days=moer_days)
+    moer = synthetic_moer(moer_days, seed=7)
+    eng = StepEngine(net, N, moer_forecast_steps=k, project_action=project, autoreset=True,
+                     device=local_rank, bank_slots=P, max_sessions=64, moer_days=moer_days)
+    eng.upload_moer(moer)
+    eng.upload_episodes(ns, sess, req, day)
+    eng.set_autoreset_stride(1)
+    eng.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    ring = [torch.rand((N, n), dtype=torch.float32, device=dev, generator=gen) for _ in range(args.ring)]
+    ptrs = [t.data_ptr() for t in ring]
+    step, out = eng.make_stepper()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(ptrs[i % len(ptrs)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(ptrs[i % len(ptrs)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- metrics all-gather (the only collective of the path; off the step critical path) ----
+    m = eng.read_metrics()
+    vec = torch.tensor([m['profit'], m['carbon_cost'], m['excess_charge'], m['env_steps'],
+                        m['episodes_finished'], m['envs_with_status']], dtype=torch.float64, device=dev)
+    if dist is not None:
+        gathered = [torch.zeros_like(vec) for _ in range(world)]
+        dist.all_gather(gathered, vec)
+        total = torch.stack(gathered).sum(0).cpu().numpy()
+    else:
+        total = vec.cpu().numpy()
+
+    # ---- per-kernel duration with HIP events on the engine's stream (rank 0) ----
+    roofline = None
+    if rank == 0:
+        eng.enable_timing(True)
+        main_ms, slow_ms = [], []
+        for i in range(args.kernel_timing_steps):
+            step(ptrs[i % len(ptrs)])
+            a, b = eng.last_step_ms()
+            main_ms.append(a)
+            slow_ms.append(b)
+        eng.enable_timing(False)
+        avg_main = float(np.mean(main_ms))
+        avg_slow = float(np.mean(slow_ms))
+        bytes_per_launch = algorithmic_bytes_per_env_step(n, k) * N
+        achieved = bytes_per_launch / (avg_main * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f'{args.site}_N{N}_project{int(project)}'
+                traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        roofline = {'bound': 'hbm', 'kernel': 'evc::step_kernel', 'achieved': round(achieved, 2),
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
+                    'traffic': traffic, 'avg_kernel_ms': round(avg_main, 5),
+                    'solver_kernel_ms': round(avg_slow, 5),
+                    'algorithmic_bytes_per_launch': bytes_per_launch}
+
+    # ---- CPU baseline: the oracle (scalar C restatement) on the host cores, bounded sample ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as ob
+        cn, cs = args.cpu_envs, args.cpu_steps
+        bat = ob.OracleBatch(ob.OracleNetwork(net), cn, k, project)
+        cns, csess, creq, cday = ns[:cn % P or P], sess, req, day
+        bat.set_bank(ns, sess, req, day, moer, autoreset_stride=1)
+        bat.reset(np.arange(cn, dtype=np.int32) % P)
+        cores = ob.max_threads()
+        acts = [r[:cn].cpu().numpy() for r in ring]
+        # skip the empty early-morning periods so that the sample has plugged-in EVs
+        for i in range(96):
+            bat.step(acts[i % len(acts)], autoreset=True, debug=False)
+        t1 = time.perf_counter()
+        for i in range(cs):
+            bat.step(acts[i % len(acts)], autoreset=True, debug=False)
+        dt = time.perf_counter() - t1
+        cpu_baseline = {'value': round(cn * cs / dt, 1), 'unit': 'env-steps/s', 'cores': cores,
+                        'kind': 'port',
+                        'sample': f'{cn} envs x {cs} steps (periods 97..{96 + cs}) of the same workload, '
+                                  f'oracle/ C restatement, OpenMP over envs'}
+
+    if rank == 0:
+        value = N * world * args.steps / elapsed
+        line = {
+            'metric': 'env-steps/sec at 65k batched 54-station EVChargingEnv; 1/2/4/8 MI355X',
+            'value': round(value, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 5),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': f'{N} batched {n}-station EVChargingEnv ({args.site}) per GPU, continuous '
+                                   f'actions, project_action_in_env={project}, autoreset over a {P}-episode bank',
+                       'envs_per_gpu': N, 'global_envs': N * world, 'parallelism': f'env-shard x{world}',
+                       'actions': 'U[0,1) float32 resident in HBM'},
+            'roofline': roofline, 'cpu_baseline': cpu_baseline,
+            'episode_metrics': {'profit': float(total[0]), 'carbon_cost': float(total[1]),
+                                'excess_charge': float(total[2]), 'episodes_finished': float(total[4]),
+                                'envs_with_status': float(total[5])},
+        }
+        print(json.dumps(line))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

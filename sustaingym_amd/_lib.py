@@ -1,0 +1,117 @@
+"""ctypes loader of the C-ABI shared library ``libevcharge_hip.so`` (include/evcharge.h).
+
+The library is the product: hand-written gfx950 HIP kernels behind a plain-C interface.  There
+is deliberately no fallback of any kind here — if the library has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C sustaingym_amd/csrc``) or
+no MI355X is visible, loading / ``evc_create`` fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libevcharge_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'evcharge.h')
+
+ABI_VERSION = 1
+MAX_STATIONS, MAX_CONSTRAINTS, MAX_GROUPS, MAX_SESSIONS = 64, 32, 16, 256
+MOER_ROWS, MOER_COLS, EPISODE_STEPS = 289, 37, 288
+
+FLAG_PROJECT_ACTION = 1 << 0
+FLAG_AUTORESET = 1 << 1
+ACTION_F32, ACTION_DISCRETE = 0, 1
+
+STATUS_OCCUPIED = 1 << 0
+STATUS_PROJ_NOCONV = 1 << 1
+STATUS_STEP_AFTER_DONE = 1 << 2
+STATUS_ACTION_CLAMPED = 1 << 3
+
+SESSION_DTYPE = np.dtype([('arrival', '<i2'), ('departure', '<i2'),
+                          ('est_departure', '<i2'), ('station', '<i2')])
+
+
+class NetworkDesc(C.Structure):
+    _fields_ = [('n_stations', C.c_int32), ('n_constraints', C.c_int32),
+                ('constraint_matrix', C.c_void_p), ('phase_angles_deg', C.c_void_p),
+                ('magnitudes', C.c_void_p), ('evse_kind', C.c_void_p)]
+
+
+class StepOut(C.Structure):
+    _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('terminated', C.c_void_p),
+                ('breakdown', C.c_void_p), ('final_obs', C.c_void_p), ('pilots', C.c_void_p),
+                ('rates', C.c_void_p), ('projected', C.c_void_p)]
+
+
+class EngineLibraryError(RuntimeError):
+    pass
+
+
+# Every symbol include/evcharge.h declares: name -> (restype, argtypes)
+_vp, _i32, _u32 = C.c_void_p, C.c_int32, C.c_uint32
+SIGNATURES = {
+    'evc_create': (_i32, [C.POINTER(NetworkDesc), _i32, _i32, _u32, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
+    'evc_destroy': (None, [_vp]),
+    'evc_last_error': (C.c_char_p, []),
+    'evc_abi_version': (_i32, []),
+    'evc_set_stream': (_i32, [_vp, _vp]),
+    'evc_synchronize': (_i32, [_vp]),
+    'evc_obs_dim': (_i32, [_vp]),
+    'evc_num_envs': (_i32, [_vp]),
+    'evc_num_stations': (_i32, [_vp]),
+    'evc_num_groups': (_i32, [_vp]),
+    'evc_upload_moer': (_i32, [_vp, _i32, _i32, _vp]),
+    'evc_upload_episodes': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'evc_set_autoreset_stride': (_i32, [_vp, _i32]),
+    'evc_reset': (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    'evc_step': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
+    'evc_reset_host': (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    'evc_step_host': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
+    'evc_get_env_scalars': (_i32, [_vp, _vp]),
+    'evc_set_env_scalars': (_i32, [_vp, _vp]),
+    'evc_get_station_state': (_i32, [_vp, _vp, _vp, _vp]),
+    'evc_set_station_state': (_i32, [_vp, _vp, _vp, _vp]),
+    'evc_get_breakdown': (_i32, [_vp, _vp]),
+    'evc_set_breakdown': (_i32, [_vp, _vp]),
+    'evc_clear_status': (_i32, [_vp]),
+    'evc_read_metrics': (_i32, [_vp, _vp]),
+    'evc_enable_timing': (_i32, [_vp, _i32]),
+    'evc_last_step_ms': (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the HIP engine library.  Raises ``EngineLibraryError`` if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineLibraryError(
+            f'{LIB_PATH} not found: the gfx950 HIP engine has not been built. Run '
+            '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C sustaingym_amd/csrc`). '
+            'There is no CPU fallback.')
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # e.g. libamdhip64 missing
+        raise EngineLibraryError(f'cannot load {LIB_PATH}: {exc}') from exc
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise EngineLibraryError(f'{LIB_PATH} does not export {name}') from exc
+        fn.restype = res
+        fn.argtypes = args
+    if lib.evc_abi_version() != ABI_VERSION:
+        raise EngineLibraryError(f'ABI version mismatch: library {lib.evc_abi_version()} != {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = '') -> None:
+    if rc != 0:
+        msg = load().evc_last_error().decode('utf-8', 'replace')
+        raise EngineLibraryError(f'{what} failed with code {rc}: {msg}')

@@ -1,0 +1,172 @@
+// evc_device.h — gfx950 device-side building blocks of the batched EV-charging step engine.
+//
+// One 64-lane wavefront simulates one environment: lane i = charging station i of the
+// network (n <= 64).  Everything that is "per environment" is wave-uniform, everything that is
+// "per station" lives in a lane.  Cross-station reductions are done with DPP row shifts /
+// row broadcasts (fp64) or with ballot + popcount on bit-planes (integer pilot sums), never
+// through memory.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "evcharge.h"
+
+namespace evc {
+
+// ---- constants of the reference (sustaingym/envs/evcharging/env.py:99-114), evaluated in the
+// same expression order as the Python source so that they carry the same float64 values ----
+struct Consts {
+    static constexpr double TIMESTEP_DURATION = 5.0;       // env.py:99
+    static constexpr double ACTION_SCALE_FACTOR = 32.0;    // env.py:100
+    static constexpr double VOLTAGE = 208.0;               // env.py:103
+    static constexpr double MARGINAL_PROFIT_PER_KWH = 0.15 * 0.20;                    // :106
+    static constexpr double A_MINS_TO_KWH = (1.0 / 60.0) * (VOLTAGE / 1000.0);        // :108
+    static constexpr double A_PERS_TO_KWH = A_MINS_TO_KWH * TIMESTEP_DURATION;        // :111
+    static constexpr double PROFIT_FACTOR = A_PERS_TO_KWH * MARGINAL_PROFIT_PER_KWH;  // :112
+    static constexpr double VIOLATION_FACTOR = A_PERS_TO_KWH * 0.001;                 // :113
+    static constexpr double CARBON_COST_FACTOR = A_PERS_TO_KWH * (30.85 / 1000.0);    // :114
+    // event_generation.py:60-62 + acnportal Linear2StageBattery defaults
+    static constexpr double BATTERY_CAPACITY = 100.0;
+    static constexpr double BATTERY_MAX_POWER = 100.0;
+    static constexpr double TRANSITION_SOC = 0.8;
+    static constexpr double FULLY_CHARGED_EPS = 1e-3;      // acnportal EV.fully_charged
+    static constexpr double PROJ_TOL = 1e-10;              // relative feasibility / KKT tolerance
+};
+
+constexpr int kWave = 64;
+constexpr int kEmptyDep = -1;          // departure value of an empty EVSE
+constexpr int kNoArrival = 0x7fff;     // next_arrival when the session list is exhausted
+
+// Per-environment scalars: two int4 per environment.
+struct EnvScalars {
+    int t, cursor, slot, moer_day;                     // int4 #0
+    int n_sessions, next_arrival, status, episodes;    // int4 #1
+};
+
+// Network tables (engine-owned, read-only, staged into LDS by each workgroup).
+struct NetTables {
+    // M[c][g] = A[c][rep(g)] * exp(j*deg2rad(phase[rep(g)])), stored [g][c] so that lane c
+    // reads consecutive addresses; only the [G][m] corner is populated.
+    double Mre[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
+    double Mim[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
+    double Aabs[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];  // |A[c][rep(g)]|
+    double mag[EVC_MAX_CONSTRAINTS];
+};
+
+// Kernel parameters (passed by value; lives in kernarg memory -> scalar loads).
+struct Params {
+    int N, n, m, G, k, F;
+    int bank_slots, max_sessions, moer_days;
+    int autoreset, autoreset_stride, project;
+    unsigned long long group_mask[EVC_MAX_GROUPS];  // lanes of each station class
+    unsigned long long cc_mask;                     // lanes with a ClipperCreek EVSE
+    // persistent state
+    double* rem;             // [N][n] remaining demand (kWh) of the plugged EV
+    int* depest;             // [N][n] departure (low 16) | est_departure (high 16)
+    int4* scal;              // [N][2]
+    double* acc;             // [N][3] cumulative profit, carbon_cost, excess_charge
+    // episode bank
+    const evc_session* sessions;   // [bank_slots][max_sessions]
+    const double* requested;       // [bank_slots][max_sessions]
+    const int* n_sessions;         // [bank_slots]
+    const int* slot_moer_day;      // [bank_slots]
+    // MOER tables
+    const double* moer_hist;       // [moer_days][289]        column 0 in float64 (reward)
+    const float* moer_obs;         // [moer_days][289][37]    float32 (observation)
+    const NetTables* tables;
+    // slow-path queue (environments whose projection needs the iterative solver)
+    int* slow_count;               // [1]
+    int* slow_list;                // [N]
+};
+
+struct StepIO {
+    const void* actions;
+    int action_kind, bins;
+    evc_step_out out;
+};
+
+// ------------------------------------------------------------------------------------------
+// wave-level primitives
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int CTRL, int ROW_MASK, bool BOUND_CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, BOUND_CTRL);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, BOUND_CTRL);
+    return __hiloint2double(hi, lo);
+}
+
+// Inclusive prefix sum over the 64 lanes (Kogge-Stone inside each 16-lane row with DPP
+// row_shr, then row_bcast:15 / row_bcast:31 to carry across rows).  Lane 63 holds the total.
+__device__ __forceinline__ double wave_scan_f64(double v) {
+    v += dpp_f64<0x111, 0xf, true>(v);   // row_shr:1
+    v += dpp_f64<0x112, 0xf, true>(v);   // row_shr:2
+    v += dpp_f64<0x114, 0xf, true>(v);   // row_shr:4
+    v += dpp_f64<0x118, 0xf, true>(v);   // row_shr:8
+    v += dpp_f64<0x142, 0xa, false>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_f64<0x143, 0xc, false>(v);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    return readlane_f64(wave_scan_f64(v), 63);
+}
+
+// Sum over the lanes in `mask` of a value that is an integer in [0, 2^BITS) on every lane:
+// BITS ballots + popcounts, entirely on the scalar unit.
+template <int BITS>
+struct BitPlanes {
+    unsigned long long plane[BITS];
+    __device__ __forceinline__ void build(int v) {
+#pragma unroll
+        for (int b = 0; b < BITS; b++) plane[b] = __ballot((v >> b) & 1);
+    }
+    __device__ __forceinline__ int sum(unsigned long long mask) const {
+        int s = 0;
+#pragma unroll
+        for (int b = 0; b < BITS; b++) s += __popcll(plane[b] & mask) << b;
+        return s;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// per-station physics
+// ------------------------------------------------------------------------------------------
+
+// env.py:366-378: normalised action -> EVSE-legal pilot (A).  y = 32 * action (float64).
+__device__ __forceinline__ double legal_pilot(double y, bool is_cc) {
+    double av = (y >= 6.0) ? rint(y) : 0.0;          // np.round = half-to-even = v_rndne_f64
+    double cc = rint(y / 8.0) * 8.0;
+    return is_cc ? cc : av;
+}
+
+// acnportal Linear2StageBattery._charge_stepwise + EV.charge for a battery of capacity 100 kWh,
+// max power 100 kW, whose headroom equals the EV's remaining demand `rem` (event_generation.py
+// :173-176 with requested <= 100).  Returns the actual rate (A) and updates rem.
+__device__ __forceinline__ double charge_ev(double pilot, double& rem) {
+    if (pilot == 0.0) return 0.0;
+    const double period_h = Consts::TIMESTEP_DURATION / 60.0;
+    double rate_to_full = rem / period_h;
+    double soc = (Consts::BATTERY_CAPACITY - rem) / Consts::BATTERY_CAPACITY;
+    double pilot_kw = pilot * Consts::VOLTAGE / 1000.0;
+    double limit = Consts::BATTERY_MAX_POWER;
+    if (!(soc < Consts::TRANSITION_SOC))
+        limit = (1.0 - soc) / (1.0 - Consts::TRANSITION_SOC) * Consts::BATTERY_MAX_POWER;
+    double p = fmin(fmin(pilot_kw, limit), rate_to_full);
+    p = fmin(p, Consts::BATTERY_MAX_POWER);
+    double amps = p * 1000.0 / Consts::VOLTAGE;
+    rem -= (amps * Consts::VOLTAGE / 1000.0) * period_h;
+    return amps;
+}
+
+}  // namespace evc

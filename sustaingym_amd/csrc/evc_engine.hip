@@ -1,0 +1,598 @@
+// evc_engine.hip — C-ABI implementation (include/evcharge.h) of the MI355X-native batched
+// EV-charging step engine.  Host-side bookkeeping only; all simulation arithmetic is in the
+// gfx950 kernels of evc_kernels.h / evc_solver.h.  There is no CPU execution path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "evc_solver.h"
+
+using namespace evc;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail(EVC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+template <typename T>
+hipError_t dmalloc(T** p, size_t count) {
+    return hipMalloc((void**)p, sizeof(T) * (count ? count : 1));
+}
+
+}  // namespace
+
+struct evc_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Params P{};
+    uint32_t flags = 0;
+    // owned device buffers
+    double* d_rem = nullptr;
+    int* d_depest = nullptr;
+    int4* d_scal = nullptr;
+    double* d_acc = nullptr;
+    evc_session* d_sessions = nullptr;
+    double* d_requested = nullptr;
+    int* d_nsess = nullptr;
+    int* d_slot_moer = nullptr;
+    double* d_moer_hist = nullptr;
+    float* d_moer_obs = nullptr;
+    NetTables* d_tables = nullptr;
+    int* d_slow_count = nullptr;
+    int* d_slow_list = nullptr;
+    int* d_idbuf = nullptr;       // reset ids/slots staging [2N]
+    double* d_metrics = nullptr;  // [8]
+    // device staging for the *_host entry points
+    void* d_act = nullptr;        // N*n*8 bytes
+    float* d_obs = nullptr;
+    double* d_reward = nullptr;
+    uint8_t* d_term = nullptr;
+    double* d_breakdown = nullptr;
+    float* d_final = nullptr;
+    double* d_pilots = nullptr;
+    double* d_rates = nullptr;
+    double* d_proj = nullptr;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_valid = false, ev_slow = false;
+    // host mirrors
+    unsigned long long env_steps = 0;
+    int step_grid = 0, solver_grid = 0;
+};
+
+namespace {
+
+int bind(evc_engine* e) {
+    HIP_TRY(hipSetDevice(e->device));
+    return EVC_OK;
+}
+
+void free_all(evc_engine* e) {
+    void* ptrs[] = {e->d_rem, e->d_depest, e->d_scal, e->d_acc, e->d_sessions, e->d_requested,
+                    e->d_nsess, e->d_slot_moer, e->d_moer_hist, e->d_moer_obs, e->d_tables,
+                    e->d_slow_count, e->d_slow_list, e->d_idbuf, e->d_metrics, e->d_act, e->d_obs,
+                    e->d_reward, e->d_term, e->d_breakdown, e->d_final, e->d_pilots, e->d_rates,
+                    e->d_proj};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+}
+
+// Station classes: identical (constraint column, phase angle).  Every constraint depends on a
+// schedule only through the per-class sums (what the kernels reduce over).
+int build_tables(const evc_network_desc* net, Params& P, NetTables& T) {
+    const int n = net->n_stations, m = net->n_constraints;
+    std::vector<int> rep;
+    std::vector<int> gid(n, -1);
+    for (int i = 0; i < n; i++) {
+        int found = -1;
+        for (size_t g = 0; g < rep.size() && found < 0; g++) {
+            const int j = rep[g];
+            bool same = net->phase_angles_deg[i] == net->phase_angles_deg[j];
+            for (int c = 0; c < m && same; c++)
+                same = net->constraint_matrix[c * n + i] == net->constraint_matrix[c * n + j];
+            if (same) found = (int)g;
+        }
+        if (found < 0) {
+            if ((int)rep.size() >= EVC_MAX_GROUPS)
+                return fail(EVC_EINVAL, "network has more than %d station classes", EVC_MAX_GROUPS);
+            found = (int)rep.size();
+            rep.push_back(i);
+        }
+        gid[i] = found;
+    }
+    P.G = (int)rep.size();
+    memset(&T, 0, sizeof(T));
+    for (int g = 0; g < EVC_MAX_GROUPS; g++) P.group_mask[g] = 0ull;
+    P.cc_mask = 0ull;
+    for (int i = 0; i < n; i++) {
+        P.group_mask[gid[i]] |= 1ull << i;
+        if (net->evse_kind[i] == EVC_EVSE_CC) P.cc_mask |= 1ull << i;
+        else if (net->evse_kind[i] != EVC_EVSE_AV)
+            return fail(EVC_EINVAL, "evse_kind[%d] = %d is not EVC_EVSE_AV/CC", i, net->evse_kind[i]);
+    }
+    for (int g = 0; g < P.G; g++) {
+        const int j = rep[g];
+        const double rad = net->phase_angles_deg[j] * (M_PI / 180.0);  // np.deg2rad, env.py:485
+        const double cs = std::cos(rad), sn = std::sin(rad);
+        for (int c = 0; c < m; c++) {
+            const double a = net->constraint_matrix[c * n + j];
+            T.Mre[g][c] = a * cs;
+            T.Mim[g][c] = a * sn;
+            T.Aabs[g][c] = std::fabs(a);
+        }
+    }
+    for (int c = 0; c < m; c++) {
+        if (!(net->magnitudes[c] > 0.0)) return fail(EVC_EINVAL, "magnitudes[%d] must be > 0", c);
+        T.mag[c] = net->magnitudes[c];
+    }
+    return EVC_OK;
+}
+
+void compute_grids(evc_engine* e) {
+    int blocks = (e->P.N + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks >= 8) blocks -= blocks % 8;
+    e->step_grid = blocks;
+    e->solver_grid = e->P.N < 2048 ? e->P.N : 2048;
+}
+
+int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bins,
+                const evc_step_out* out) {
+    if (!actions_dev || !out || !out->obs || !out->reward || !out->terminated)
+        return fail(EVC_EINVAL, "evc_step: actions, out->obs, out->reward, out->terminated required");
+    if (action_kind != EVC_ACTION_F32 && action_kind != EVC_ACTION_DISCRETE)
+        return fail(EVC_EINVAL, "evc_step: unknown action_kind %d", action_kind);
+    if (action_kind == EVC_ACTION_DISCRETE && bins < 2)
+        return fail(EVC_EINVAL, "evc_step: discrete actions need bins >= 2");
+    StepIO io;
+    io.actions = actions_dev;
+    io.action_kind = action_kind;
+    io.bins = bins;
+    io.out = *out;
+    if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+    if (e->P.project) {
+        HIP_TRY(hipMemsetAsync(e->d_slow_count, 0, sizeof(int), e->stream));
+        hipLaunchKernelGGL(step_kernel<true>, dim3(e->step_grid), dim3(256), 0, e->stream, e->P, io);
+        if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+        hipLaunchKernelGGL(solver_step_kernel, dim3(e->solver_grid), dim3(64), 0, e->stream, e->P, io);
+    } else {
+        hipLaunchKernelGGL(step_kernel<false>, dim3(e->step_grid), dim3(256), 0, e->stream, e->P, io);
+        if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+    }
+    if (e->timing) {
+        HIP_TRY(hipEventRecord(e->ev[2], e->stream));
+        e->ev_valid = true;
+        e->ev_slow = e->P.project != 0;
+    }
+    HIP_TRY(hipGetLastError());
+    e->env_steps += (unsigned long long)e->P.N;
+    return EVC_OK;
+}
+
+int ensure_staging(evc_engine* e) {
+    if (e->d_obs) return EVC_OK;
+    const size_t N = e->P.N, n = e->P.n, F = e->P.F;
+    HIP_TRY(hipMalloc(&e->d_act, N * n * 8));
+    HIP_TRY(dmalloc(&e->d_obs, N * F));
+    HIP_TRY(dmalloc(&e->d_reward, N));
+    HIP_TRY(dmalloc(&e->d_term, N));
+    HIP_TRY(dmalloc(&e->d_breakdown, N * 3));
+    HIP_TRY(dmalloc(&e->d_final, N * F));
+    HIP_TRY(dmalloc(&e->d_pilots, N * n));
+    HIP_TRY(dmalloc(&e->d_rates, N * n));
+    HIP_TRY(dmalloc(&e->d_proj, N * n));
+    HIP_TRY(hipMemset(e->d_final, 0, sizeof(float) * N * F));
+    return EVC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* evc_last_error(void) { return g_err; }
+int evc_abi_version(void) { return EVC_ABI_VERSION; }
+
+int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_t flags,
+               int32_t device, int32_t bank_slots, int32_t max_sessions, int32_t moer_days,
+               evc_engine** out) {
+    if (!out) return fail(EVC_EINVAL, "evc_create: out is NULL");
+    *out = nullptr;
+    if (!net || !net->constraint_matrix || !net->phase_angles_deg || !net->magnitudes || !net->evse_kind)
+        return fail(EVC_EINVAL, "evc_create: incomplete network descriptor");
+    if (net->n_stations < 1 || net->n_stations > EVC_MAX_STATIONS)
+        return fail(EVC_EINVAL, "evc_create: n_stations must be in [1,%d]", EVC_MAX_STATIONS);
+    if (net->n_constraints < 0 || net->n_constraints > EVC_MAX_CONSTRAINTS)
+        return fail(EVC_EINVAL, "evc_create: n_constraints must be in [0,%d]", EVC_MAX_CONSTRAINTS);
+    if (num_envs < 1) return fail(EVC_EINVAL, "evc_create: num_envs must be >= 1");
+    if (k < 1 || k > 36) return fail(EVC_EINVAL, "evc_create: moer_forecast_steps must be in [1,36]");
+    if (bank_slots < 1 || max_sessions < 1 || max_sessions > EVC_MAX_SESSIONS || moer_days < 1)
+        return fail(EVC_EINVAL, "evc_create: bad bank_slots/max_sessions/moer_days");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(EVC_ENODEV, "evc_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(EVC_ENODEV, "evc_create: device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (prop.warpSize != 64)
+        return fail(EVC_ENODEV, "evc_create: device wavefront size %d != 64 (%s)", prop.warpSize, prop.gcnArchName);
+
+    evc_engine* e = new evc_engine();
+    e->device = device;
+    e->flags = flags;
+    Params& P = e->P;
+    P.N = num_envs;
+    P.n = net->n_stations;
+    P.m = net->n_constraints;
+    P.k = k;
+    P.F = 2 * P.n + k + 2;
+    P.bank_slots = bank_slots;
+    P.max_sessions = max_sessions;
+    P.moer_days = moer_days;
+    P.autoreset = (flags & EVC_FLAG_AUTORESET) ? 1 : 0;
+    P.autoreset_stride = 1;
+    P.project = (flags & EVC_FLAG_PROJECT_ACTION) ? 1 : 0;
+    NetTables T;
+    int rc = build_tables(net, P, T);
+    if (rc != EVC_OK) { delete e; return rc; }
+
+    const size_t N = P.N, n = P.n;
+    hipError_t err = hipSuccess;
+    auto A = [&](hipError_t x) { if (err == hipSuccess) err = x; };
+    A(dmalloc(&e->d_rem, N * n));
+    A(dmalloc(&e->d_depest, N * n));
+    A(dmalloc(&e->d_scal, N * 2));
+    A(dmalloc(&e->d_acc, N * 3));
+    A(dmalloc(&e->d_sessions, (size_t)bank_slots * max_sessions));
+    A(dmalloc(&e->d_requested, (size_t)bank_slots * max_sessions));
+    A(dmalloc(&e->d_nsess, (size_t)bank_slots));
+    A(dmalloc(&e->d_slot_moer, (size_t)bank_slots));
+    A(dmalloc(&e->d_moer_hist, (size_t)moer_days * EVC_MOER_ROWS));
+    A(dmalloc(&e->d_moer_obs, (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
+    A(dmalloc(&e->d_tables, 1));
+    A(dmalloc(&e->d_slow_count, 1));
+    A(dmalloc(&e->d_slow_list, N));
+    A(dmalloc(&e->d_idbuf, 2 * N));
+    A(dmalloc(&e->d_metrics, 8));
+    if (err != hipSuccess) {
+        free_all(e);
+        delete e;
+        return fail(EVC_ENOMEM, "evc_create: hipMalloc failed: %s", hipGetErrorString(err));
+    }
+    A(hipMemset(e->d_rem, 0, sizeof(double) * N * n));
+    A(hipMemset(e->d_depest, 0xff, sizeof(int) * N * n));
+    A(hipMemset(e->d_scal, 0, sizeof(int4) * N * 2));
+    A(hipMemset(e->d_acc, 0, sizeof(double) * N * 3));
+    A(hipMemset(e->d_sessions, 0, sizeof(evc_session) * (size_t)bank_slots * max_sessions));
+    A(hipMemset(e->d_requested, 0, sizeof(double) * (size_t)bank_slots * max_sessions));
+    A(hipMemset(e->d_nsess, 0, sizeof(int) * (size_t)bank_slots));
+    A(hipMemset(e->d_slot_moer, 0, sizeof(int) * (size_t)bank_slots));
+    A(hipMemset(e->d_moer_hist, 0, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS));
+    A(hipMemset(e->d_moer_obs, 0, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
+    A(hipMemset(e->d_slow_count, 0, sizeof(int)));
+    A(hipMemcpy(e->d_tables, &T, sizeof(T), hipMemcpyHostToDevice));
+    for (auto& ev : e->ev) A(hipEventCreate(&ev));
+    if (err != hipSuccess) {
+        free_all(e);
+        delete e;
+        return fail(EVC_EHIP, "evc_create: device init failed: %s", hipGetErrorString(err));
+    }
+    // a fresh engine is "terminated" until the first reset: t = 288
+    {
+        std::vector<int4> init(N * 2);
+        for (size_t i = 0; i < N; i++) {
+            init[2 * i] = make_int4(EVC_EPISODE_STEPS, 0, 0, 0);
+            init[2 * i + 1] = make_int4(0, kNoArrival, 0, 0);
+        }
+        A(hipMemcpy(e->d_scal, init.data(), sizeof(int4) * N * 2, hipMemcpyHostToDevice));
+    }
+    P.rem = e->d_rem; P.depest = e->d_depest; P.scal = e->d_scal; P.acc = e->d_acc;
+    P.sessions = e->d_sessions; P.requested = e->d_requested; P.n_sessions = e->d_nsess;
+    P.slot_moer_day = e->d_slot_moer; P.moer_hist = e->d_moer_hist; P.moer_obs = e->d_moer_obs;
+    P.tables = e->d_tables; P.slow_count = e->d_slow_count; P.slow_list = e->d_slow_list;
+    compute_grids(e);
+    *out = e;
+    return EVC_OK;
+}
+
+void evc_destroy(evc_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    free_all(e);
+    delete e;
+}
+
+int evc_set_stream(evc_engine* e, void* s) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    e->stream = (hipStream_t)s;
+    return EVC_OK;
+}
+
+int evc_synchronize(evc_engine* e) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return EVC_OK;
+}
+
+int evc_obs_dim(const evc_engine* e) { return e ? e->P.F : EVC_EINVAL; }
+int evc_num_envs(const evc_engine* e) { return e ? e->P.N : EVC_EINVAL; }
+int evc_num_stations(const evc_engine* e) { return e ? e->P.n : EVC_EINVAL; }
+int evc_num_groups(const evc_engine* e) { return e ? e->P.G : EVC_EINVAL; }
+
+int evc_upload_moer(evc_engine* e, int32_t first_day, int32_t num_days, const double* moer) {
+    if (!e || !moer) return fail(EVC_EINVAL, "evc_upload_moer: null argument");
+    if (first_day < 0 || num_days < 1 || first_day + num_days > e->P.moer_days)
+        return fail(EVC_EINVAL, "evc_upload_moer: days [%d,%d) outside capacity %d", first_day,
+                    first_day + num_days, e->P.moer_days);
+    if (int rc = bind(e)) return rc;
+    const size_t rows = (size_t)num_days * EVC_MOER_ROWS;
+    std::vector<double> hist(rows);
+    std::vector<float> obs(rows * EVC_MOER_COLS);
+    for (size_t r = 0; r < rows; r++) {
+        hist[r] = moer[r * EVC_MOER_COLS];                       // env.py:455 uses float64 col 0
+        for (int c = 0; c < EVC_MOER_COLS; c++)                  // env.py:390-391 casts to float32
+            obs[r * EVC_MOER_COLS + c] = (float)moer[r * EVC_MOER_COLS + c];
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_moer_hist + (size_t)first_day * EVC_MOER_ROWS, hist.data(),
+                      sizeof(double) * rows, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_moer_obs + (size_t)first_day * EVC_MOER_ROWS * EVC_MOER_COLS, obs.data(),
+                      sizeof(float) * rows * EVC_MOER_COLS, hipMemcpyHostToDevice));
+    return EVC_OK;
+}
+
+int evc_upload_episodes(evc_engine* e, int32_t first_slot, int32_t count, int32_t stride,
+                        const int32_t* n_sessions, const evc_session* sessions,
+                        const double* requested, const int32_t* moer_day) {
+    if (!e || !n_sessions || !sessions || !requested || !moer_day)
+        return fail(EVC_EINVAL, "evc_upload_episodes: null argument");
+    const Params& P = e->P;
+    if (first_slot < 0 || count < 1 || first_slot + count > P.bank_slots)
+        return fail(EVC_EINVAL, "evc_upload_episodes: slots [%d,%d) outside bank of %d", first_slot,
+                    first_slot + count, P.bank_slots);
+    if (stride < 1) return fail(EVC_EINVAL, "evc_upload_episodes: stride must be >= 1");
+    std::vector<evc_session> s((size_t)count * P.max_sessions);
+    std::vector<double> rq((size_t)count * P.max_sessions, 0.0);
+    memset(s.data(), 0, sizeof(evc_session) * s.size());
+    for (int i = 0; i < count; i++) {
+        const int ns = n_sessions[i];
+        if (ns < 0 || ns > P.max_sessions || ns > stride)
+            return fail(EVC_EINVAL, "episode %d: %d sessions exceed capacity %d", i, ns, P.max_sessions);
+        if (moer_day[i] < 0 || moer_day[i] >= P.moer_days)
+            return fail(EVC_EINVAL, "episode %d: moer_day %d outside [0,%d)", i, moer_day[i], P.moer_days);
+        for (int j = 0; j < ns; j++) {
+            const evc_session& x = sessions[(size_t)i * stride + j];
+            const double r = requested[(size_t)i * stride + j];
+            if (x.arrival < 0 || x.arrival > EVC_EPISODE_STEPS || x.departure < 0 ||
+                x.departure > EVC_EPISODE_STEPS)
+                return fail(EVC_EINVAL, "episode %d session %d: timestamps outside [0,288]", i, j);
+            if (x.station < 0 || x.station >= P.n)
+                return fail(EVC_EINVAL, "episode %d session %d: station %d outside [0,%d)", i, j, x.station, P.n);
+            if (j > 0 && x.arrival < sessions[(size_t)i * stride + j - 1].arrival)
+                return fail(EVC_EINVAL, "episode %d: sessions must be sorted by arrival", i);
+            if (!(r >= 0.0) || r > Consts::BATTERY_CAPACITY)
+                return fail(EVC_EINVAL, "episode %d session %d: requested energy %g outside [0,100] kWh "
+                            "(requested_energy_cap > battery capacity is unsupported)", i, j, r);
+            s[(size_t)i * P.max_sessions + j] = x;
+            rq[(size_t)i * P.max_sessions + j] = r;
+        }
+    }
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_sessions + (size_t)first_slot * P.max_sessions, s.data(),
+                      sizeof(evc_session) * s.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_requested + (size_t)first_slot * P.max_sessions, rq.data(),
+                      sizeof(double) * rq.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_nsess + first_slot, n_sessions, sizeof(int) * count, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_slot_moer + first_slot, moer_day, sizeof(int) * count, hipMemcpyHostToDevice));
+    return EVC_OK;
+}
+
+int evc_set_autoreset_stride(evc_engine* e, int32_t stride) {
+    if (!e || stride < 0) return fail(EVC_EINVAL, "evc_set_autoreset_stride: bad argument");
+    e->P.autoreset_stride = stride % e->P.bank_slots;
+    return EVC_OK;
+}
+
+int evc_reset(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_t* slots,
+              float* obs_dev) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    const Params& P = e->P;
+    if (count < 1 || count > P.N) return fail(EVC_EINVAL, "evc_reset: count %d outside [1,%d]", count, P.N);
+    if (int rc = bind(e)) return rc;
+    const int* d_ids = nullptr;
+    const int* d_slots = nullptr;
+    if (env_ids) {
+        for (int i = 0; i < count; i++)
+            if (env_ids[i] < 0 || env_ids[i] >= P.N) return fail(EVC_EINVAL, "evc_reset: env id %d", env_ids[i]);
+        HIP_TRY(hipMemcpyAsync(e->d_idbuf, env_ids, sizeof(int) * count, hipMemcpyHostToDevice, e->stream));
+        d_ids = e->d_idbuf;
+    }
+    if (slots) {
+        for (int i = 0; i < count; i++)
+            if (slots[i] < 0 || slots[i] >= P.bank_slots) return fail(EVC_EINVAL, "evc_reset: slot %d", slots[i]);
+        HIP_TRY(hipMemcpyAsync(e->d_idbuf + P.N, slots, sizeof(int) * count, hipMemcpyHostToDevice, e->stream));
+        d_slots = e->d_idbuf + P.N;
+    }
+    hipLaunchKernelGGL(reset_kernel, dim3((count + 3) / 4), dim3(256), 0, e->stream, e->P, d_ids,
+                       d_slots, count, obs_dev);
+    HIP_TRY(hipGetLastError());
+    if (env_ids || slots) HIP_TRY(hipStreamSynchronize(e->stream));  // host id buffers may be reused
+    return EVC_OK;
+}
+
+int evc_step(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
+             const evc_step_out* out) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    if (int rc = bind(e)) return rc;
+    return launch_step(e, actions_dev, action_kind, bins, out);
+}
+
+int evc_reset_host(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_t* slots,
+                   float* obs_host) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    if (int rc = bind(e)) return rc;
+    if (int rc = ensure_staging(e)) return rc;
+    if (int rc = evc_reset(e, env_ids, count, slots, e->d_obs)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (obs_host)
+        HIP_TRY(hipMemcpy(obs_host, e->d_obs, sizeof(float) * (size_t)e->P.N * e->P.F, hipMemcpyDeviceToHost));
+    return EVC_OK;
+}
+
+int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, int32_t bins,
+                  const evc_step_out* oh) {
+    if (!e || !actions_host || !oh) return fail(EVC_EINVAL, "evc_step_host: null argument");
+    if (int rc = bind(e)) return rc;
+    if (int rc = ensure_staging(e)) return rc;
+    const size_t N = e->P.N, n = e->P.n, F = e->P.F;
+    const size_t abytes = N * n * (action_kind == EVC_ACTION_DISCRETE ? 8 : 4);
+    HIP_TRY(hipMemcpyAsync(e->d_act, actions_host, abytes, hipMemcpyHostToDevice, e->stream));
+    evc_step_out od;
+    od.obs = e->d_obs; od.reward = e->d_reward; od.terminated = e->d_term;
+    od.breakdown = e->d_breakdown; od.final_obs = e->d_final;
+    od.pilots = oh->pilots ? e->d_pilots : nullptr;
+    od.rates = oh->rates ? e->d_rates : nullptr;
+    od.projected = oh->projected ? e->d_proj : nullptr;
+    if (int rc = launch_step(e, e->d_act, action_kind, bins, &od)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (oh->obs) HIP_TRY(hipMemcpy(oh->obs, e->d_obs, sizeof(float) * N * F, hipMemcpyDeviceToHost));
+    if (oh->reward) HIP_TRY(hipMemcpy(oh->reward, e->d_reward, sizeof(double) * N, hipMemcpyDeviceToHost));
+    if (oh->terminated) HIP_TRY(hipMemcpy(oh->terminated, e->d_term, N, hipMemcpyDeviceToHost));
+    if (oh->breakdown) HIP_TRY(hipMemcpy(oh->breakdown, e->d_breakdown, sizeof(double) * N * 3, hipMemcpyDeviceToHost));
+    if (oh->final_obs) HIP_TRY(hipMemcpy(oh->final_obs, e->d_final, sizeof(float) * N * F, hipMemcpyDeviceToHost));
+    if (oh->pilots) HIP_TRY(hipMemcpy(oh->pilots, e->d_pilots, sizeof(double) * N * n, hipMemcpyDeviceToHost));
+    if (oh->rates) HIP_TRY(hipMemcpy(oh->rates, e->d_rates, sizeof(double) * N * n, hipMemcpyDeviceToHost));
+    if (oh->projected) HIP_TRY(hipMemcpy(oh->projected, e->d_proj, sizeof(double) * N * n, hipMemcpyDeviceToHost));
+    return EVC_OK;
+}
+
+int evc_get_env_scalars(evc_engine* e, int32_t* out_host) {
+    if (!e || !out_host) return fail(EVC_EINVAL, "null argument");
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out_host, e->d_scal, sizeof(int4) * 2 * (size_t)e->P.N, hipMemcpyDeviceToHost));
+    return EVC_OK;
+}
+
+int evc_set_env_scalars(evc_engine* e, const int32_t* in_host) {
+    if (!e || !in_host) return fail(EVC_EINVAL, "null argument");
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_scal, in_host, sizeof(int4) * 2 * (size_t)e->P.N, hipMemcpyHostToDevice));
+    return EVC_OK;
+}
+
+int evc_get_station_state(evc_engine* e, double* rem, int16_t* dep, int16_t* est) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    if (int rc = bind(e)) return rc;
+    const size_t cnt = (size_t)e->P.N * e->P.n;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (rem) HIP_TRY(hipMemcpy(rem, e->d_rem, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    if (dep || est) {
+        std::vector<int> de(cnt);
+        HIP_TRY(hipMemcpy(de.data(), e->d_depest, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; i++) {
+            if (dep) dep[i] = (int16_t)(de[i] & 0xffff);
+            if (est) est[i] = (int16_t)(de[i] >> 16);
+        }
+    }
+    return EVC_OK;
+}
+
+int evc_set_station_state(evc_engine* e, const double* rem, const int16_t* dep, const int16_t* est) {
+    if (!e || !rem || !dep || !est) return fail(EVC_EINVAL, "null argument");
+    if (int rc = bind(e)) return rc;
+    const size_t cnt = (size_t)e->P.N * e->P.n;
+    std::vector<int> de(cnt);
+    for (size_t i = 0; i < cnt; i++) de[i] = ((int)dep[i] & 0xffff) | ((int)est[i] << 16);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_rem, rem, sizeof(double) * cnt, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_depest, de.data(), sizeof(int) * cnt, hipMemcpyHostToDevice));
+    return EVC_OK;
+}
+
+int evc_get_breakdown(evc_engine* e, double* out_host) {
+    if (!e || !out_host) return fail(EVC_EINVAL, "null argument");
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out_host, e->d_acc, sizeof(double) * 3 * (size_t)e->P.N, hipMemcpyDeviceToHost));
+    return EVC_OK;
+}
+
+int evc_set_breakdown(evc_engine* e, const double* in_host) {
+    if (!e || !in_host) return fail(EVC_EINVAL, "null argument");
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_acc, in_host, sizeof(double) * 3 * (size_t)e->P.N, hipMemcpyHostToDevice));
+    return EVC_OK;
+}
+
+int evc_clear_status(evc_engine* e) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    std::vector<int> sc((size_t)e->P.N * 8);
+    if (int rc = evc_get_env_scalars(e, sc.data())) return rc;
+    for (int i = 0; i < e->P.N; i++) sc[(size_t)i * 8 + 6] = 0;
+    return evc_set_env_scalars(e, sc.data());
+}
+
+int evc_read_metrics(evc_engine* e, double* out_host) {
+    if (!e || !out_host) return fail(EVC_EINVAL, "null argument");
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipMemsetAsync(e->d_metrics, 0, sizeof(double) * 8, e->stream));
+    int blocks = (e->P.N + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(metrics_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->d_metrics);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out_host, e->d_metrics, sizeof(double) * 8, hipMemcpyDeviceToHost));
+    out_host[3] = (double)e->env_steps;
+    return EVC_OK;
+}
+
+int evc_enable_timing(evc_engine* e, int32_t on) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    e->timing = on != 0;
+    e->ev_valid = false;
+    return EVC_OK;
+}
+
+int evc_last_step_ms(evc_engine* e, float* ms_main, float* ms_slow) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    if (!e->ev_valid) return fail(EVC_ESTATE, "evc_last_step_ms: no timed step recorded");
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipEventSynchronize(e->ev[2]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+    if (ms_main) *ms_main = a;
+    if (ms_slow) *ms_slow = e->ev_slow ? b : 0.f;
+    return EVC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,296 @@
+// evc_solver.h — iterative action projection for the environments the main kernel queued.
+//
+// Problem (reference: env.py:178-221 + magnitude_constraint env.py:473-500, a cvxpy/MOSEK SOCP),
+// in amps y = 32 x:
+//     min 1/2 ||y - b||^2   s.t.  0 <= y <= h,   || M_c S(y) || <= r_c   (c < m)
+// where S_g(y) = sum of y over station class g.  Conic dual with one 2-vector multiplier per row:
+//     q(z) = min_{0<=y<=h} 1/2||y-b||^2 + sum_c ( z_c . M_c S(y) - r_c ||z_c|| )
+// whose inner minimiser is the clip  y_i = clip(b_i - nu_g(i), 0, h_i),  nu = sum_c M_c^T z_c.
+// q is concave with gradient  w_c - r_c z_c/||z_c||  (w_c = M_c S); z_c = 0 is optimal iff
+// ||w_c|| <= r_c.  We ascend q with a Levenberg-Marquardt Newton direction on the active rows
+// (Hessian  M_A diag(k_g) M_A^T + r_c/||z_c|| (I - z^ z^T), k_g = number of unclamped stations
+// of class g) and a line search on the sign of the directional derivative (expand on flat
+// pieces, halve on overshoot).  One "pass" = one clip + class sums; everything else is tiny
+// dense algebra shared by the wave through LDS.
+//
+// One workgroup = one wavefront = one environment (lane i: station i; lane c: constraint row c;
+// lane a: row a of the Newton system).
+#pragma once
+
+#include "evc_kernels.h"
+
+namespace evc {
+
+constexpr int kMaxActive = 16;              // rows simultaneously in the Newton system
+constexpr int kMaxDim = 2 * kMaxActive;
+constexpr int kSolverMaxIter = 100;
+
+struct SolverLds {
+    LdsNet net;
+    double z[EVC_MAX_CONSTRAINTS][2];       // accepted multipliers
+    double zt[EVC_MAX_CONSTRAINTS][2];      // trial multipliers
+    double w[EVC_MAX_CONSTRAINTS][2];       // M_c S at the last pass
+    double nu[EVC_MAX_GROUPS];
+    double S[EVC_MAX_GROUPS];
+    double kfree[EVC_MAX_GROUPS];
+    double H[kMaxDim][kMaxDim + 1];
+    double dir[kMaxDim];
+    int act[kMaxActive];
+};
+
+struct SolverLane {
+    double b, h;       // target / cap of this station (amps)
+    int gid;           // station class of this lane (-1 outside the network)
+    double y;          // current clip
+};
+
+// one station pass at multipliers zsrc: fills L.nu, L.S, L.kfree, L.w; lane.y
+__device__ __forceinline__ void solver_pass(const Params& P, SolverLds& L, SolverLane& ln, int lane,
+                                            double (*zsrc)[2]) {
+    const int m = P.m, G = P.G;
+    if (lane < G) {
+        double nu = 0.0;
+        for (int c = 0; c < m; c++)
+            nu += L.net.Mre[lane][c] * zsrc[c][0] + L.net.Mim[lane][c] * zsrc[c][1];
+        L.nu[lane] = nu;
+    }
+    __syncthreads();
+    double v = 0.0;
+    bool is_free = false;
+    ln.y = 0.0;
+    if (ln.gid >= 0) {
+        v = ln.b - L.nu[ln.gid];
+        ln.y = fmin(fmax(v, 0.0), ln.h);
+        is_free = (v > 0.0) && (v <= ln.h) && (ln.h > 0.0);
+    }
+    const unsigned long long free_mask = __ballot(is_free);
+    for (int g = 0; g < G; g++) {
+        const double s = wave_sum_f64(ln.gid == g ? ln.y : 0.0);
+        if (lane == 0) {
+            L.S[g] = s;
+            L.kfree[g] = (double)__popcll(free_mask & P.group_mask[g]);
+        }
+    }
+    __syncthreads();
+    if (lane < m) {
+        double re = 0.0, im = 0.0;
+        for (int g = 0; g < G; g++) {
+            re += L.net.Mre[g][lane] * L.S[g];
+            im += L.net.Mim[g][lane] * L.S[g];
+        }
+        L.w[lane][0] = re;
+        L.w[lane][1] = im;
+    }
+    __syncthreads();
+}
+
+// gradient of q for row c = lane at multipliers zsrc (0 for inactive rows)
+__device__ __forceinline__ void row_gradient(const SolverLds& L, int m, int lane, double (*zsrc)[2],
+                                             double& g0, double& g1, double& nz, double& nw) {
+    g0 = g1 = nz = nw = 0.0;
+    if (lane < m) {
+        const double z0 = zsrc[lane][0], z1 = zsrc[lane][1];
+        const double w0 = L.w[lane][0], w1 = L.w[lane][1];
+        nz = sqrt(z0 * z0 + z1 * z1);
+        nw = sqrt(w0 * w0 + w1 * w1);
+        if (nz > 0.0) {
+            g0 = w0 - L.net.mag[lane] * z0 / nz;
+            g1 = w1 - L.net.mag[lane] * z1 / nz;
+        }
+    }
+}
+
+// trial point z + alpha * dir (rows whose multiplier would cross zero are deactivated); runs a
+// pass there and returns the directional derivative per unit alpha.
+__device__ __forceinline__ double solver_trial(const Params& P, SolverLds& L, SolverLane& ln, int lane,
+                                               unsigned long long active, double alpha) {
+    const int m = P.m;
+    if (lane < m) {
+        double t0 = L.z[lane][0], t1 = L.z[lane][1];
+        if ((active >> lane) & 1ull) {
+            const int j = __popcll(active & ((1ull << lane) - 1ull));
+            const double z0 = t0, z1 = t1;
+            t0 = z0 + alpha * L.dir[2 * j];
+            t1 = z1 + alpha * L.dir[2 * j + 1];
+            if (t0 * z0 + t1 * z1 <= 0.0) t0 = t1 = 0.0;
+        }
+        L.zt[lane][0] = t0;
+        L.zt[lane][1] = t1;
+    }
+    __syncthreads();
+    solver_pass(P, L, ln, lane, L.zt);
+    double g0, g1, nz, nw;
+    row_gradient(L, m, lane, L.zt, g0, g1, nz, nw);
+    double dd = 0.0;
+    if (lane < m && ((active >> lane) & 1ull))
+        dd = g0 * (L.zt[lane][0] - L.z[lane][0]) + g1 * (L.zt[lane][1] - L.z[lane][1]);
+    return wave_sum_f64(dd) / alpha;
+}
+
+__device__ __forceinline__ void accept_trial(SolverLds& L, int m, int lane) {
+    if (lane < m) { L.z[lane][0] = L.zt[lane][0]; L.z[lane][1] = L.zt[lane][1]; }
+    __syncthreads();
+}
+
+// In-LDS Cholesky solve of the d x d system (lane a owns row a and rhs a); result in L.dir.
+__device__ __forceinline__ void solver_cholesky(SolverLds& L, int d, int lane, double rhs) {
+    for (int j = 0; j < d; j++) {
+        double t = 0.0;
+        if (lane >= j && lane < d) {
+            t = L.H[lane][j];
+            for (int k = 0; k < j; k++) t -= L.H[lane][k] * L.H[j][k];
+        }
+        double piv = readlane_f64(t, j);
+        piv = piv < 1e-300 ? 1e-300 : piv;
+        const double ljj = sqrt(piv);
+        __syncthreads();
+        if (lane == j) L.H[j][j] = ljj;
+        else if (lane > j && lane < d) L.H[lane][j] = t / ljj;
+        __syncthreads();
+    }
+    // forward substitution L u = rhs
+    for (int i = 0; i < d; i++) {
+        double xi = readlane_f64(rhs, i) / L.H[i][i];
+        if (lane == i) rhs = xi;
+        else if (lane > i && lane < d) rhs -= L.H[lane][i] * xi;
+    }
+    // back substitution L^T x = u
+    for (int i = d - 1; i >= 0; i--) {
+        double xi = readlane_f64(rhs, i) / L.H[i][i];
+        if (lane == i) rhs = xi;
+        else if (lane < i) rhs -= L.H[i][lane] * xi;
+    }
+    if (lane < d) L.dir[lane] = rhs;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
+    __shared__ SolverLds L;
+    stage_net(L.net, P);
+    const int lane = threadIdx.x;
+    const int n = P.n, m = P.m, G = P.G;
+    const int count = rfl(*P.slow_count);
+    SolverLane ln;
+    ln.gid = -1;
+    for (int g = 0; g < G; g++)
+        if (lane < n && ((P.group_mask[g] >> lane) & 1ull)) ln.gid = g;
+
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        const int env = rfl(P.slow_list[q]);
+        EnvRegs r;
+        load_env(P, env, lane, r);
+        bool clamped;
+        const double a = load_action(P, io, env, lane, clamped);
+        ln.b = a * Consts::ACTION_SCALE_FACTOR;
+        ln.h = demand_cap_amps(r);
+        if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; }
+        __syncthreads();
+        solver_pass(P, L, ln, lane, L.z);
+
+        double mu = 1e-3;
+        bool converged = false;
+        for (int it = 0; it < kSolverMaxIter; it++) {
+            double g0, g1, nz, nw;
+            row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
+            const double rc = lane < m ? L.net.mag[lane] : 1.0;
+            // activate violated rows that have no multiplier yet
+            const bool newly = lane < m && nz == 0.0 && nw > rc * (1.0 + Consts::PROJ_TOL);
+            if (__ballot(newly) != 0ull) {
+                if (newly) {
+                    L.z[lane][0] = 1e-6 * L.w[lane][0] / nw;
+                    L.z[lane][1] = 1e-6 * L.w[lane][1] / nw;
+                }
+                __syncthreads();
+                solver_pass(P, L, ln, lane, L.z);
+                row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
+            }
+            unsigned long long active = __ballot(lane < m && nz > 0.0);
+            // convergence test
+            double res = 0.0;
+            if (lane < m) res = (nz > 0.0) ? sqrt(g0 * g0 + g1 * g1) / rc : (nw / rc - 1.0);
+            if (__ballot(res > Consts::PROJ_TOL) == 0ull) { converged = true; break; }
+            // keep the Newton system within kMaxActive rows (drop the least violated extras)
+            while (__popcll(active) > kMaxActive) {
+                const int last = 63 - __clzll(active);
+                active &= ~(1ull << last);
+            }
+            const int na = __popcll(active);
+            const int d = 2 * na;
+            const bool mine = lane < m && ((active >> lane) & 1ull);
+            const int jrow = __popcll(active & ((1ull << lane) - 1ull));
+            if (mine) L.act[jrow] = lane;
+            __syncthreads();
+            // build H (lane a owns row a = 2*j + p  <->  row act[j], component p)
+            double rhs = 0.0;
+            if (lane < d) {
+                const int ja = lane >> 1, pa = lane & 1, ca = L.act[ja];
+                double diag = 0.0;
+                for (int bcol = 0; bcol < d; bcol++) {
+                    const int jb = bcol >> 1, pb = bcol & 1, cb = L.act[jb];
+                    double hsum = 0.0;
+                    for (int g = 0; g < G; g++) {
+                        const double ma = pa ? L.net.Mim[g][ca] : L.net.Mre[g][ca];
+                        const double mb = pb ? L.net.Mim[g][cb] : L.net.Mre[g][cb];
+                        hsum += ma * L.kfree[g] * mb;
+                    }
+                    if (jb == ja) {
+                        const double z0 = L.z[ca][0], z1 = L.z[ca][1];
+                        const double nzc = sqrt(z0 * z0 + z1 * z1);
+                        const double za = (pa ? z1 : z0) / nzc, zb = (pb ? z1 : z0) / nzc;
+                        hsum += (L.net.mag[ca] / nzc) * ((pa == pb ? 1.0 : 0.0) - za * zb);
+                    }
+                    L.H[lane][bcol] = hsum;
+                    if (bcol == lane) diag = hsum;
+                }
+                // gradient component of this row
+                const double z0 = L.z[ca][0], z1 = L.z[ca][1];
+                const double nzc = sqrt(z0 * z0 + z1 * z1);
+                rhs = L.w[ca][pa] - L.net.mag[ca] * (pa ? z1 : z0) / nzc;
+                L.dir[lane] = diag;   // temporarily: diagonal, for the trace
+            }
+            __syncthreads();
+            double tr = wave_sum_f64(lane < d ? L.dir[lane] : 0.0);
+            double scale = tr / (double)d;
+            scale = scale < 1e-12 ? 1e-12 : scale;
+            if (lane < d) L.H[lane][lane] += mu * scale;
+            __syncthreads();
+            const double grad_a = rhs;
+            solver_cholesky(L, d, lane, rhs);
+            const double dd0 = wave_sum_f64(lane < d ? grad_a * L.dir[lane] : 0.0);
+
+            // line search on the sign of the directional derivative
+            double alpha = 1.0;
+            double dd = solver_trial(P, L, ln, lane, active, alpha);
+            if (dd > 0.25 * dd0) {
+                // undershoot (flat piece): expand while the derivative stays positive
+                accept_trial(L, m, lane);         // alpha = 1 is an ascent point
+                double best_alpha = 1.0;
+                // z was overwritten: trials are taken relative to the ORIGINAL point, so keep
+                // the displacement bookkeeping simple by expanding from the accepted point.
+                while (dd > 0.25 * dd0 && best_alpha < 1e6) {
+                    const double dd2 = solver_trial(P, L, ln, lane, active, 3.0 * best_alpha);
+                    if (dd2 < -0.5 * dd0) break;
+                    accept_trial(L, m, lane);
+                    best_alpha *= 4.0;
+                    dd = dd2;
+                }
+                mu = fmax(mu * 0.1, 1e-12);
+            } else {
+                int nback = 0;
+                while (dd < -0.5 * dd0 && alpha > 1e-8) {
+                    alpha *= 0.5;
+                    nback++;
+                    dd = solver_trial(P, L, ln, lane, active, alpha);
+                }
+                accept_trial(L, m, lane);
+                mu = (nback > 1) ? mu * 4.0 : fmax(mu * 0.25, 1e-12);
+            }
+            solver_pass(P, L, ln, lane, L.z);     // state of the accepted point
+        }
+        if (!converged) r.status |= EVC_STATUS_PROJ_NOCONV;
+        finish_step(P, io, L.net, env, lane, ln.y, ln.y / Consts::ACTION_SCALE_FACTOR, clamped, r);
+        __syncthreads();
+    }
+}
+
+}  // namespace evc

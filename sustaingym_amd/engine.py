@@ -1,0 +1,285 @@
+"""Python handle on the C-ABI step engine (include/evcharge.h).
+
+``StepEngine`` is plumbing only: it marshals numpy / torch buffers into the C calls.  Device
+buffers are torch CUDA(HIP) tensors (PyTorch is used for device memory and streams, nothing
+else); numpy inputs go through the ``*_host`` entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any
+
+import numpy as np
+
+from . import _lib
+from ._lib import SESSION_DTYPE, NetworkDesc, StepOut, check
+from .network import ChargingNetwork
+
+
+def _np_ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class StepEngine:
+    """Batched EVChargingEnv.step()/reset() engine for ``num_envs`` environments on one GPU.
+
+    Replaces, for a batch, ``EVChargingEnv.__init__/reset/step/close`` of the reference
+    (sustaingym/envs/evcharging/env.py:116-176, 293-338, 229-291, 466-470).
+    """
+
+    def __init__(self, network: ChargingNetwork, num_envs: int, moer_forecast_steps: int = 36,
+                 project_action: bool = True, autoreset: bool = False, device: int = 0,
+                 bank_slots: int | None = None, max_sessions: int = 128, moer_days: int = 1,
+                 debug_outputs: bool = False):
+        self.lib = _lib.load()
+        self.network = network
+        self.N = int(num_envs)
+        self.n = network.num_stations
+        self.k = int(moer_forecast_steps)
+        self.F = 2 * self.n + self.k + 2
+        self.project_action = bool(project_action)
+        self.autoreset = bool(autoreset)
+        self.device = int(device)
+        self.bank_slots = int(bank_slots if bank_slots is not None else num_envs)
+        self.max_sessions = int(max_sessions)
+        self.moer_days = int(moer_days)
+        self.debug_outputs = bool(debug_outputs)
+        self.autoreset_stride = 1
+        self._A = np.ascontiguousarray(network.constraint_matrix, dtype=np.float64)
+        self._ph = np.ascontiguousarray(network.phase_angles, dtype=np.float64)
+        self._mag = np.ascontiguousarray(network.magnitudes, dtype=np.float64)
+        self._kind = np.ascontiguousarray(network.evse_kind, dtype=np.uint8)
+        desc = NetworkDesc(self.n, self._A.shape[0], _np_ptr(self._A), _np_ptr(self._ph),
+                           _np_ptr(self._mag), _np_ptr(self._kind))
+        flags = (_lib.FLAG_PROJECT_ACTION if project_action else 0) | \
+                (_lib.FLAG_AUTORESET if autoreset else 0)
+        handle = C.c_void_p()
+        check(self.lib.evc_create(C.byref(desc), self.N, self.k, flags, self.device,
+                                  self.bank_slots, self.max_sessions, self.moer_days,
+                                  C.byref(handle)), 'evc_create')
+        self.handle = handle
+        self._dev_out: dict[str, Any] | None = None
+        self._host_out: dict[str, np.ndarray] | None = None
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self) -> None:
+        if getattr(self, 'handle', None):
+            self.lib.evc_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_groups(self) -> int:
+        return self.lib.evc_num_groups(self.handle)
+
+    # ------------------------------------------------------------------ episode data
+    def upload_moer(self, moer: np.ndarray, first_day: int = 0) -> None:
+        """moer: float64 [D, 289, 37] (``get_moer()`` matrices, event_generation.py:209-218)."""
+        moer = np.ascontiguousarray(moer, dtype=np.float64)
+        if moer.ndim == 2:
+            moer = moer[None]
+        assert moer.shape[1:] == (_lib.MOER_ROWS, _lib.MOER_COLS), moer.shape
+        check(self.lib.evc_upload_moer(self.handle, first_day, moer.shape[0], _np_ptr(moer)),
+              'evc_upload_moer')
+
+    def upload_episodes(self, n_sessions, sessions, requested, moer_day, first_slot: int = 0) -> None:
+        """Episodes = event tables (arrival-sorted sessions) + MOER day slot per episode."""
+        n_sessions = np.ascontiguousarray(n_sessions, dtype=np.int32)
+        sessions = np.ascontiguousarray(sessions, dtype=SESSION_DTYPE)
+        requested = np.ascontiguousarray(requested, dtype=np.float64)
+        moer_day = np.ascontiguousarray(moer_day, dtype=np.int32)
+        if sessions.ndim == 1:
+            sessions, requested = sessions[None], requested[None]
+        count, stride = sessions.shape
+        assert requested.shape == (count, stride) and n_sessions.shape == (count,) == moer_day.shape
+        check(self.lib.evc_upload_episodes(self.handle, first_slot, count, stride, _np_ptr(n_sessions),
+                                           _np_ptr(sessions), _np_ptr(requested), _np_ptr(moer_day)),
+              'evc_upload_episodes')
+
+    def set_autoreset_stride(self, stride: int) -> None:
+        check(self.lib.evc_set_autoreset_stride(self.handle, int(stride)), 'evc_set_autoreset_stride')
+        self.autoreset_stride = int(stride) % self.bank_slots
+
+    # ------------------------------------------------------------------ device buffers
+    def _torch(self):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.EngineLibraryError('no HIP device visible to torch')
+        return torch
+
+    def _bind_stream(self) -> None:
+        torch = self._torch()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.evc_set_stream(self.handle, C.c_void_p(stream)), 'evc_set_stream')
+
+    def device_outputs(self) -> dict[str, Any]:
+        if self._dev_out is None:
+            torch = self._torch()
+            dev = torch.device('cuda', self.device)
+            N, n, F = self.N, self.n, self.F
+            out = {
+                'obs': torch.zeros((N, F), dtype=torch.float32, device=dev),
+                'reward': torch.zeros((N,), dtype=torch.float64, device=dev),
+                'terminated': torch.zeros((N,), dtype=torch.uint8, device=dev),
+                'breakdown': torch.zeros((N, 3), dtype=torch.float64, device=dev),
+                'final_obs': torch.zeros((N, F), dtype=torch.float32, device=dev),
+            }
+            if self.debug_outputs:
+                for key in ('pilots', 'rates', 'projected'):
+                    out[key] = torch.zeros((N, n), dtype=torch.float64, device=dev)
+            self._dev_out = out
+        return self._dev_out
+
+    def _step_out_struct(self, bufs: dict[str, Any], ptr) -> StepOut:
+        so = StepOut()
+        for name, _ in StepOut._fields_:
+            setattr(so, name, ptr(bufs[name]) if name in bufs else None)
+        return so
+
+    # ------------------------------------------------------------------ hot path
+    def reset(self, env_ids=None, slots=None, host: bool = False):
+        """EVChargingEnv.reset for a set of environments; returns the [N, F] observation buffer."""
+        ids = None if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        sl = None if slots is None else np.ascontiguousarray(slots, dtype=np.int32)
+        count = self.N if ids is None else len(ids)
+        if sl is not None:
+            assert len(sl) == count
+        if host:
+            out = self._host_buffers()
+            check(self.lib.evc_reset_host(self.handle, _np_ptr(ids), count, _np_ptr(sl),
+                                          _np_ptr(out['obs'])), 'evc_reset_host')
+            return out['obs']
+        self._bind_stream()
+        out = self.device_outputs()
+        check(self.lib.evc_reset(self.handle, _np_ptr(ids), count, _np_ptr(sl),
+                                 C.c_void_p(out['obs'].data_ptr())), 'evc_reset')
+        return out['obs']
+
+    def step(self, actions, bins: int = 0):
+        """EVChargingEnv.step for all environments.
+
+        ``actions``: torch CUDA tensor ``[N, n]`` (float32, or int64 with ``bins``) -> returns the
+        dict of device output tensors (asynchronous on the current torch stream); or a numpy
+        array -> synchronous host path returning numpy arrays.
+        """
+        if isinstance(actions, np.ndarray):
+            return self._step_host(actions, bins)
+        torch = self._torch()
+        assert actions.is_cuda and actions.shape == (self.N, self.n) and actions.is_contiguous()
+        if bins > 0:
+            assert actions.dtype == torch.int64
+            kind = _lib.ACTION_DISCRETE
+        else:
+            assert actions.dtype == torch.float32
+            kind = _lib.ACTION_F32
+        self._bind_stream()
+        out = self.device_outputs()
+        so = self._step_out_struct(out, lambda t: C.c_void_p(t.data_ptr()))
+        check(self.lib.evc_step(self.handle, C.c_void_p(actions.data_ptr()), kind, bins, C.byref(so)),
+              'evc_step')
+        return out
+
+    def make_stepper(self, bins: int = 0):
+        """Lean per-step callable for rollout loops: binds the current torch stream once and
+        returns ``(step(ptr: int) -> None, outputs)`` where ``ptr`` is the device address of a
+        contiguous ``[N, n]`` action tensor (float32, or int64 when ``bins > 0``)."""
+        self._bind_stream()
+        out = self.device_outputs()
+        so = self._step_out_struct(out, lambda t: C.c_void_p(t.data_ptr()))
+        ref = C.byref(so)
+        fn, handle = self.lib.evc_step, self.handle
+        kind = _lib.ACTION_DISCRETE if bins > 0 else _lib.ACTION_F32
+
+        def step(ptr: int, _keep=so) -> None:
+            rc = fn(handle, ptr, kind, bins, ref)
+            if rc:
+                check(rc, 'evc_step')
+        return step, out
+
+    def _host_buffers(self) -> dict[str, np.ndarray]:
+        if self._host_out is None:
+            N, n, F = self.N, self.n, self.F
+            out = {
+                'obs': np.zeros((N, F), np.float32), 'reward': np.zeros(N, np.float64),
+                'terminated': np.zeros(N, np.uint8), 'breakdown': np.zeros((N, 3), np.float64),
+                'final_obs': np.zeros((N, F), np.float32),
+            }
+            if self.debug_outputs:
+                for key in ('pilots', 'rates', 'projected'):
+                    out[key] = np.zeros((N, n), np.float64)
+            self._host_out = out
+        return self._host_out
+
+    def _step_host(self, actions: np.ndarray, bins: int):
+        assert actions.shape == (self.N, self.n)
+        if bins > 0:
+            a = np.ascontiguousarray(actions, dtype=np.int64)
+            kind = _lib.ACTION_DISCRETE
+        else:
+            a = np.ascontiguousarray(actions, dtype=np.float32)
+            kind = _lib.ACTION_F32
+        out = self._host_buffers()
+        so = self._step_out_struct(out, _np_ptr)
+        check(self.lib.evc_step_host(self.handle, _np_ptr(a), kind, bins, C.byref(so)), 'evc_step_host')
+        return out
+
+    def synchronize(self) -> None:
+        check(self.lib.evc_synchronize(self.handle), 'evc_synchronize')
+
+    # ------------------------------------------------------------------ state access
+    def env_scalars(self) -> dict[str, np.ndarray]:
+        raw = np.zeros((self.N, 8), dtype=np.int32)
+        check(self.lib.evc_get_env_scalars(self.handle, _np_ptr(raw)), 'evc_get_env_scalars')
+        names = ('t', 'cursor', 'slot', 'moer_day', 'n_sessions', 'next_arrival', 'status', 'episodes')
+        return {k: raw[:, i].copy() for i, k in enumerate(names)}
+
+    def station_state(self):
+        rem = np.zeros((self.N, self.n), np.float64)
+        dep = np.zeros((self.N, self.n), np.int16)
+        est = np.zeros((self.N, self.n), np.int16)
+        check(self.lib.evc_get_station_state(self.handle, _np_ptr(rem), _np_ptr(dep), _np_ptr(est)),
+              'evc_get_station_state')
+        return rem, dep, est
+
+    def get_state(self) -> dict[str, np.ndarray]:
+        """Checkpoint of the whole simulator state (the reference has none)."""
+        raw = np.zeros((self.N, 8), dtype=np.int32)
+        check(self.lib.evc_get_env_scalars(self.handle, _np_ptr(raw)), 'evc_get_env_scalars')
+        rem, dep, est = self.station_state()
+        acc = np.zeros((self.N, 3), np.float64)
+        check(self.lib.evc_get_breakdown(self.handle, _np_ptr(acc)), 'evc_get_breakdown')
+        return {'scalars': raw, 'remaining_kwh': rem, 'departure': dep, 'est_departure': est,
+                'breakdown': acc}
+
+    def set_state(self, state: dict[str, np.ndarray]) -> None:
+        raw = np.ascontiguousarray(state['scalars'], dtype=np.int32)
+        rem = np.ascontiguousarray(state['remaining_kwh'], dtype=np.float64)
+        dep = np.ascontiguousarray(state['departure'], dtype=np.int16)
+        est = np.ascontiguousarray(state['est_departure'], dtype=np.int16)
+        acc = np.ascontiguousarray(state['breakdown'], dtype=np.float64)
+        check(self.lib.evc_set_env_scalars(self.handle, _np_ptr(raw)), 'evc_set_env_scalars')
+        check(self.lib.evc_set_station_state(self.handle, _np_ptr(rem), _np_ptr(dep), _np_ptr(est)),
+              'evc_set_station_state')
+        check(self.lib.evc_set_breakdown(self.handle, _np_ptr(acc)), 'evc_set_breakdown')
+
+    def clear_status(self) -> None:
+        check(self.lib.evc_clear_status(self.handle), 'evc_clear_status')
+
+    def read_metrics(self) -> dict[str, float]:
+        out = np.zeros(8, np.float64)
+        check(self.lib.evc_read_metrics(self.handle, _np_ptr(out)), 'evc_read_metrics')
+        return {'profit': out[0], 'carbon_cost': out[1], 'excess_charge': out[2],
+                'env_steps': out[3], 'episodes_finished': out[4], 'envs_with_status': out[5]}
+
+    def enable_timing(self, on: bool = True) -> None:
+        check(self.lib.evc_enable_timing(self.handle, int(on)), 'evc_enable_timing')
+
+    def last_step_ms(self) -> tuple[float, float]:
+        a, b = C.c_float(), C.c_float()
+        check(self.lib.evc_last_step_ms(self.handle, C.byref(a), C.byref(b)), 'evc_last_step_ms')
+        return a.value, b.value

@@ -1,0 +1,57 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/evcharge.h declares (no compute calls without a GPU), and fails loudly without one."""
+import re
+
+import pytest
+
+from sustaingym_amd import _lib
+
+
+def declared_symbols():
+    text = open(_lib.HEADER_PATH).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(evc_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.evc_abi_version() == _lib.ABI_VERSION
+
+
+def test_constants_match_header():
+    text = open(_lib.HEADER_PATH).read()
+    for name, val in (('EVC_MAX_STATIONS', _lib.MAX_STATIONS), ('EVC_MAX_CONSTRAINTS', _lib.MAX_CONSTRAINTS),
+                      ('EVC_MAX_GROUPS', _lib.MAX_GROUPS), ('EVC_MAX_SESSIONS', _lib.MAX_SESSIONS),
+                      ('EVC_MOER_ROWS', _lib.MOER_ROWS), ('EVC_MOER_COLS', _lib.MOER_COLS),
+                      ('EVC_EPISODE_STEPS', _lib.EPISODE_STEPS), ('EVC_ABI_VERSION', _lib.ABI_VERSION)):
+        m = re.search(rf'#define\s+{name}\s+(\d+)', text)
+        assert m and int(m.group(1)) == val, name
+    assert _lib.SESSION_DTYPE.itemsize == 8
+
+
+def test_no_cpu_fallback_fails_loudly(caltech):
+    """Without a GPU evc_create must fail (ENODEV) — there is no CPU path in the product."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from sustaingym_amd.engine import StepEngine
+    with pytest.raises(_lib.EngineLibraryError, match='no HIP device|ENODEV|code -2'):
+        StepEngine(caltech, 4)
+
+
+def test_product_does_not_import_oracle():
+    import os
+    root = os.path.dirname(_lib.__file__)
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.lower() or f in (), (f, 'product code must not reference the oracle')

@@ -1,0 +1,176 @@
+"""GPU parity tests proper: the HIP engine (through the C-ABI) against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact integers (pilots, est_departures, event state, done flags),
+floats within 1e-9 relative (north_star asks for 1e-5)."""
+import numpy as np
+import pytest
+
+from helpers import assert_step_parity, make_pair, make_workload
+
+pytestmark = pytest.mark.gpu
+
+
+def run_episode(eng, bat, n, steps, action_fn, bins=0, autoreset=False, tag=''):
+    g_obs = eng.reset(host=True).copy()
+    o_obs = bat.reset()
+    assert np.array_equal(g_obs, o_obs), 'reset obs'
+    status = np.zeros(bat.N, np.uint32)
+    for t in range(steps):
+        a = action_fn(t)
+        g = eng.step(a, bins=bins)
+        o = bat.step(a, bins=bins, autoreset=autoreset)
+        status |= o['status']
+        assert_step_parity(g, o, n, tag=f'{tag} step {t + 1}')
+        if autoreset and o['terminated'].any():
+            d = o['terminated'].astype(bool)
+            assert np.array_equal(g['final_obs'][d][:, n:], o['final_obs'][d][:, n:])
+    sc = eng.env_scalars()
+    assert np.array_equal(sc['status'].astype(np.uint32) & 0xB, status & 0xB), tag
+    rem_g, dep_g, est_g = eng.station_state()
+    return status
+
+
+@pytest.mark.parametrize('project', [False, True])
+def test_caltech_continuous_full_episode(caltech, project):
+    """configs[1]-style: batched Caltech envs, continuous actions, one full 288-step episode."""
+    N = 192
+    wl = make_workload(caltech, N, seed=3)
+    eng, bat = make_pair(caltech, N, wl, project)
+    rng = np.random.default_rng(0)
+    n = caltech.num_stations
+    run_episode(eng, bat, n, 288, lambda t: rng.random((N, n), dtype=np.float32), tag=f'caltech proj={project}')
+    # state parity at the end of the episode
+    sc = eng.env_scalars()
+    assert np.all(sc['t'] == 288) and np.all(sc['episodes'] == 1)
+    eng.close()
+
+
+def test_caltech_discrete_single_env(caltech):
+    """configs[0]: N=1, Caltech, DiscreteActionWrapper(bins=5) actions, projection on."""
+    wl = make_workload(caltech, 1, seed=11)
+    eng, bat = make_pair(caltech, 1, wl, project=True)
+    rng = np.random.default_rng(0)
+    n = caltech.num_stations
+    run_episode(eng, bat, n, 288, lambda t: rng.integers(0, 5, (1, n)), bins=5, tag='discrete N=1')
+    eng.close()
+
+
+def test_busy_network_projection_active(caltech):
+    """Many simultaneous EVs + full-rate actions: pod and transformer constraints bind, so the
+    iterative solver path is exercised on most steps."""
+    N = 64
+    wl = make_workload(caltech, N, seed=5, busy=True)
+    eng, bat = make_pair(caltech, N, wl, project=True)
+    rng = np.random.default_rng(1)
+    n = caltech.num_stations
+
+    def act(t):
+        if t % 3 == 0:
+            return np.ones((N, n), np.float32)
+        if t % 3 == 1:
+            return (rng.random((N, n)) < 0.8).astype(np.float32)
+        return rng.uniform(0.5, 1.0, (N, n)).astype(np.float32)
+    status = run_episode(eng, bat, n, 200, act, tag='busy')
+    assert not (status & 2).any(), 'oracle projection failed to converge'
+    sc = eng.env_scalars()
+    assert not (sc['status'] & 2).any(), 'HIP projection failed to converge'
+    eng.close()
+
+
+def test_jpl_projection_off_and_on(jpl):
+    """configs[2]-style (JPL, 52 stations; provisional topology) at test size."""
+    N = 96
+    n = jpl.num_stations
+    for project in (False, True):
+        wl = make_workload(jpl, N, seed=7, busy=project)
+        eng, bat = make_pair(jpl, N, wl, project)
+        rng = np.random.default_rng(2)
+        run_episode(eng, bat, n, 120, lambda t: rng.random((N, n), dtype=np.float32) ** 0.3,
+                    tag=f'jpl proj={project}')
+        eng.close()
+
+
+def test_autoreset_walks_the_bank(caltech):
+    """gymnasium-0.28 VectorEnv autoreset: terminal obs in final_obs, next episode = slot + stride."""
+    N, P = 32, 80
+    wl = make_workload(caltech, N, bank_slots=P, seed=9)
+    eng, bat = make_pair(caltech, N, wl, project=False, autoreset=True, stride=N)
+    rng = np.random.default_rng(3)
+    n = caltech.num_stations
+    run_episode(eng, bat, n, 288 * 2 + 5, lambda t: rng.random((N, n), dtype=np.float32), autoreset=True,
+                tag='autoreset')
+    sc = eng.env_scalars()
+    assert np.all(sc['episodes'] == 2) and np.all(sc['t'] == 5)
+    assert np.array_equal(sc['slot'], (np.arange(N) + 2 * N) % P)
+    eng.close()
+
+
+def test_edge_cases(caltech):
+    """Empty episodes, out-of-range / NaN actions (clamped + flagged), step after termination."""
+    from sustaingym_amd import _lib
+    N = 8
+    n = caltech.num_stations
+    wl = make_workload(caltech, N, seed=13)
+    wl['n_sessions'][:4] = 0                      # empty days
+    eng, bat = make_pair(caltech, N, wl, project=True)
+    rng = np.random.default_rng(4)
+
+    def act(t):
+        a = rng.random((N, n), dtype=np.float32) * 1.4 - 0.2     # outside [0,1]
+        if t == 7:
+            a[0, 0] = np.nan
+        return a
+    run_episode(eng, bat, n, 288, act, tag='edge')
+    sc = eng.env_scalars()
+    assert np.all(sc['status'] & _lib.STATUS_ACTION_CLAMPED)
+    # step after termination: ignored + flagged, terminated stays set
+    g = eng.step(np.zeros((N, n), np.float32))
+    assert np.all(g['terminated'] == 1) and np.all(g['reward'] == 0)
+    sc = eng.env_scalars()
+    assert np.all(sc['status'] & _lib.STATUS_STEP_AFTER_DONE) and np.all(sc['t'] == 288)
+    eng.close()
+
+
+def test_device_tensor_path_matches_host_path(caltech):
+    """evc_step with torch device tensors (async, on torch's stream) == evc_step_host."""
+    import torch
+    N = 64
+    n = caltech.num_stations
+    wl = make_workload(caltech, N, seed=17)
+    eng_d, _ = make_pair(caltech, N, wl, project=True)
+    eng_h, _ = make_pair(caltech, N, wl, project=True)
+    obs_d = eng_d.reset()
+    obs_h = eng_h.reset(host=True)
+    assert np.array_equal(obs_d.cpu().numpy(), obs_h)
+    rng = np.random.default_rng(5)
+    for t in range(60):
+        a = rng.random((N, n), dtype=np.float32)
+        out_d = eng_d.step(torch.from_numpy(a).cuda())
+        out_h = eng_h.step(a)
+        for key in ('obs', 'reward', 'terminated', 'breakdown', 'pilots', 'rates'):
+            assert np.array_equal(out_d[key].cpu().numpy(), out_h[key]), (key, t)
+    m = eng_d.read_metrics()
+    assert m['env_steps'] == 60 * N
+    assert abs(m['profit'] - out_h['breakdown'][:, 0].sum()) < 1e-9
+    eng_d.close()
+    eng_h.close()
+
+
+def test_checkpoint_roundtrip(caltech):
+    """get_state / set_state: restoring a snapshot replays bit-identically."""
+    N = 16
+    n = caltech.num_stations
+    wl = make_workload(caltech, N, seed=19)
+    eng, _ = make_pair(caltech, N, wl, project=True)
+    eng.reset(host=True)
+    rng = np.random.default_rng(6)
+    acts = [rng.random((N, n), dtype=np.float32) for _ in range(80)]
+    for a in acts[:40]:
+        eng.step(a)
+    snap = eng.get_state()
+    first = [{k: v.copy() for k, v in eng.step(a).items()} for a in acts[40:]]
+    eng.set_state(snap)
+    for a, ref in zip(acts[40:], first):
+        out = eng.step(a)
+        for key in ref:
+            assert np.array_equal(out[key], ref[key]), key
+    eng.close()
