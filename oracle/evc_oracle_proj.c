@@ -137,7 +137,9 @@ static double try_step(pctx* p, double z[MMAX][2], const int* act, int na, const
 int orc_project_action_impl(const orc_net* net, const double* action, const float* demands,
                             double* x_out, double* kkt_out) {
     const int n = net->n, m = net->m;
-    const double TOL = 1e-10;
+    const double TOL = 1e-10;      /* feasibility: rows within (1+TOL) r count as satisfied   */
+    const double TOL_KKT = 1e-12;  /* dual-gradient residual the Newton ascent is driven to   */
+    const double TOL_ACCEPT = 1e-9; /* accepted (status ok) if the iteration budget runs out  */
     /* env.py:108,111 */
     const double A_MINS_TO_KWH = (1.0 / 60.0) * (208.0 / 1000.0);
     const double A_PERS_TO_KWH = A_MINS_TO_KWH * 5.0;
@@ -169,7 +171,8 @@ int orc_project_action_impl(const orc_net* net, const double* action, const floa
     if (!need) converged = 1;
 
     double mu = 1e-3;
-    for (int it = 0; it < 200 && !converged; it++) {
+    int last_ok = 0;
+    for (int it = 0; it < 60 && !converged; it++) {
         double g[MMAX][2], nz[MMAX], nw[MMAX];
         gradient(p, z, g, nz, nw);
         int newly = 0;
@@ -195,10 +198,11 @@ int orc_project_action_impl(const orc_net* net, const double* action, const floa
                 if (rr > res_inact) res_inact = rr;
             }
         }
-        if (res_act <= TOL && res_inact <= TOL) {
+        if (res_act <= TOL_KKT && res_inact <= TOL) {
             converged = 1;
             break;
         }
+        last_ok = (res_act <= TOL_ACCEPT && res_inact <= TOL);
         /* H = B_A diag(free) B_A' + tangential curvature + LM */
         static __thread double H[DMAX][DMAX];
         double rhs[DMAX];
@@ -271,7 +275,21 @@ int orc_project_action_impl(const orc_net* net, const double* action, const floa
         station_pass(p, z); /* state of the accepted point */
     }
 
-    for (int i = 0; i < n; i++) x_out[i] = p->y[i] / 32.0;
+    if (!converged && last_ok) converged = 1;
+    /* Tie snap: values the solver moved are snapped to a 2^-16 A grid before the reference's
+     * rounding rule (env.py:373-378) sees them.  Exact optima that sit on a rounding boundary
+     * (e.g. an 80 A pod shared by 4 EVs -> 20 A -> rint(2.5)) are thereby rounded the same way by
+     * every solver that is within ~1e-6 A of the optimum; the reference's interior-point answer
+     * is itself only that accurate there. */
+    for (int i = 0; i < n; i++) {
+        double y0 = b[i] < h[i] ? b[i] : h[i];
+        double y = p->y[i];
+        if (y != y0) {
+            y = rint(y * 65536.0) / 65536.0;
+            if (y > h[i]) y = h[i];
+        }
+        x_out[i] = y / 32.0;
+    }
 
     /* ---- KKT certificate from primal quantities and multiplier magnitudes only ---- */
     if (kkt_out) {

@@ -31,7 +31,10 @@ struct Consts {
     static constexpr double BATTERY_MAX_POWER = 100.0;
     static constexpr double TRANSITION_SOC = 0.8;
     static constexpr double FULLY_CHARGED_EPS = 1e-3;      // acnportal EV.fully_charged
-    static constexpr double PROJ_TOL = 1e-10;              // relative feasibility / KKT tolerance
+    static constexpr double PROJ_TOL = 1e-10;              // rows within (1+tol) r count as satisfied
+    static constexpr double PROJ_TOL_KKT = 1e-12;          // dual-gradient residual target of the solver
+    static constexpr double PROJ_TOL_ACCEPT = 1e-9;        // accepted if the iteration budget runs out
+    static constexpr double TIE_SNAP = 65536.0;            // solver outputs snapped to 2^-16 A
 };
 
 constexpr int kWave = 64;

@@ -23,7 +23,7 @@ namespace evc {
 
 constexpr int kMaxActive = 16;              // rows simultaneously in the Newton system
 constexpr int kMaxDim = 2 * kMaxActive;
-constexpr int kSolverMaxIter = 100;
+constexpr int kSolverMaxIter = 60;
 
 struct SolverLds {
     LdsNet net;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
         solver_pass(P, L, ln, lane, L.z);
 
         double mu = 1e-3;
-        bool converged = false;
+        bool converged = false, last_ok = false;
         for (int it = 0; it < kSolverMaxIter; it++) {
             double g0, g1, nz, nw;
             row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
@@ -207,8 +207,17 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
             unsigned long long active = __ballot(lane < m && nz > 0.0);
             // convergence test
             double res = 0.0;
-            if (lane < m) res = (nz > 0.0) ? sqrt(g0 * g0 + g1 * g1) / rc : (nw / rc - 1.0);
-            if (__ballot(res > Consts::PROJ_TOL) == 0ull) { converged = true; break; }
+            bool inact = true;
+            if (lane < m) {
+                inact = !(nz > 0.0);
+                res = inact ? (nw / rc - 1.0) : sqrt(g0 * g0 + g1 * g1) / rc;
+            }
+            const unsigned long long bad_inact = __ballot(inact && res > Consts::PROJ_TOL);
+            if (bad_inact == 0ull && __ballot(!inact && res > Consts::PROJ_TOL_KKT) == 0ull) {
+                converged = true;
+                break;
+            }
+            last_ok = bad_inact == 0ull && __ballot(!inact && res > Consts::PROJ_TOL_ACCEPT) == 0ull;
             // keep the Newton system within kMaxActive rows (drop the least violated extras)
             while (__popcll(active) > kMaxActive) {
                 const int last = 63 - __clzll(active);
@@ -287,8 +296,12 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
             }
             solver_pass(P, L, ln, lane, L.z);     // state of the accepted point
         }
-        if (!converged) r.status |= EVC_STATUS_PROJ_NOCONV;
-        finish_step(P, io, L.net, env, lane, ln.y, ln.y / Consts::ACTION_SCALE_FACTOR, clamped, r);
+        if (!converged && !last_ok) r.status |= EVC_STATUS_PROJ_NOCONV;
+        // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
+        // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
+        double y = ln.y;
+        if (y != fmin(ln.b, ln.h)) y = fmin(rint(y * Consts::TIE_SNAP) / Consts::TIE_SNAP, ln.h);
+        finish_step(P, io, L.net, env, lane, y, y / Consts::ACTION_SCALE_FACTOR, clamped, r);
         __syncthreads();
     }
 }

@@ -227,10 +227,12 @@ def test_k7_projection_kkt_and_scipy(onet, net):
         a = rng.uniform(0, 1, n) if trial % 3 else np.ones(n)
         x, rc, kkt = onet.project(a, dem)
         assert rc == 0
-        assert kkt[0] < 1e-7 and kkt[1] < 1e-9 and kkt[2] < 1e-6 and kkt[3] < 1e-6
+        # KKT certificate of the converged point (before the 2^-16 A tie snap)
+        assert kkt[0] < 1e-9 and kkt[1] < 1e-10 and kkt[2] < 1e-8 and kkt[3] < 1e-8
         u = np.minimum(1.0, dem.astype(np.float64) / A_PERS_TO_KWH / 32)
-        assert np.all(x >= -1e-15) and np.all(x <= u + 1e-15)
-        assert np.all(np.abs(At @ x) * 32 <= r * (1 + 1e-9))
+        assert np.all(x >= 0) and np.all(x <= u)
+        # the returned point is the optimum snapped to a 2^-16 A grid: feasible to n * 2^-17 A
+        assert np.all(np.abs(At @ x) * 32 <= r + n * 2.0 ** -17)
         if trial < 12:
             cons = [{'type': 'ineq', 'fun': (lambda v, c=c: r[c] ** 2 - (np.abs(At[c] @ v) * 32) ** 2)}
                     for c in range(len(r))]
@@ -239,7 +241,7 @@ def test_k7_projection_kkt_and_scipy(onet, net):
                            options={'ftol': 1e-15, 'maxiter': 400})
             worst = max(worst, np.max(np.abs(ref.x - x)))
             # our point is feasible and at least as close to `a` as SciPy's
-            assert np.sum((x - a) ** 2) <= np.sum((ref.x - a) ** 2) + 1e-8
+            assert np.sum((x - a) ** 2) <= np.sum((ref.x - a) ** 2) + 1e-5  # snap + SLSQP slack
     assert worst < 1e-4
 
 
