@@ -94,6 +94,12 @@ def load() -> C.CDLL:
             f'{LIB_PATH} not found: the gfx950 HIP engine has not been built. Run '
             '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C sustaingym_amd/csrc`). '
             'There is no CPU fallback.')
+    # PyTorch-ROCm bundles its own libamdhip64; if it is going to be used in this process it
+    # must be the one HIP runtime both sides share, so let it load first.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional plumbing: the host-buffer entry points do not need it
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:  # e.g. libamdhip64 missing
