@@ -1,0 +1,29 @@
+"""MI355X-native batched step() engine for SustainGym's EV-charging environments.
+
+Public surface (mirrors ``sustaingym.envs.evcharging``):
+
+    EVChargingEnv, MultiAgentEVChargingEnv, DiscreteActionWrapper      (reference API)
+    EVChargingVectorEnv, SB3VecEnv                                      (batched API)
+    RealTraceGenerator, GMMsTraceGenerator                              (episode generators)
+    StepEngine                                                          (C-ABI handle)
+
+The HIP library is loaded lazily (``sustaingym_amd._lib.load``); importing the package does not
+need a GPU, constructing an environment does.
+"""
+from .network import ChargingNetwork, caltech_acn, jpl_acn, site_str_to_site  # noqa: F401
+from .event_generation import (AbstractTraceGenerator, EventTable, GMMsTraceGenerator,  # noqa: F401
+                               MOERLoader, RealTraceGenerator)
+
+
+def __getattr__(name):
+    if name == 'StepEngine':
+        from .engine import StepEngine
+        return StepEngine
+    if name in ('EVChargingEnv', 'MultiAgentEVChargingEnv', 'DiscreteActionWrapper',
+                'EVChargingVectorEnv', 'SB3VecEnv'):
+        from . import envs
+        return getattr(envs, name)
+    raise AttributeError(name)
+
+
+__version__ = '0.1.0'

@@ -1,0 +1,526 @@
+"""Drop-in environment classes over the HIP step engine.
+
+Same names, constructor arguments, spaces, return conventions and error behaviour as the
+reference's API layer:
+
+* :class:`EVChargingEnv`            <- sustaingym/envs/evcharging/env.py:20 (gymnasium.Env)
+* :class:`DiscreteActionWrapper`    <- sustaingym/envs/wrappers.py:13
+* :class:`MultiAgentEVChargingEnv`  <- sustaingym/envs/evcharging/multiagent_env.py:18 (PettingZoo Parallel)
+* :class:`EVChargingVectorEnv`      <- what SB3 ``SubprocVecEnv`` / RLLib rollout workers provide
+  around the reference env (train_stable_baselines.py:271-275): N environments, Gymnasium-0.28
+  ``VectorEnv`` semantics (autoreset, ``final_observation``), backed by ONE engine call per step.
+* :class:`SB3VecEnv`                <- stable_baselines3 ``VecEnv`` protocol adapter.
+
+All arithmetic of ``step()`` runs in the HIP kernels through the C-ABI; these classes only move
+buffers and keep host-side episode bookkeeping (generators, max_profit).
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Sequence
+
+import numpy as np
+
+from . import spaces
+from .engine import StepEngine
+from .event_generation import AbstractTraceGenerator, EventTable
+from .network import site_str_to_site
+
+try:  # pragma: no cover
+    import gymnasium as _gym
+    _EnvBase = _gym.Env
+except Exception:
+    _gym = None
+    _EnvBase = object
+
+MAX_SESSIONS = 256
+OBS_KEYS = ('demands', 'est_departures', 'forecasted_moer', 'prev_moer', 'timestep')  # sorted
+
+
+def obs_slices(n: int, k: int) -> dict[str, slice]:
+    """Position of each Dict key inside the flattened observation row (gymnasium sorts keys)."""
+    return {'demands': slice(0, n), 'est_departures': slice(n, 2 * n),
+            'forecasted_moer': slice(2 * n, 2 * n + k), 'prev_moer': slice(2 * n + k, 2 * n + k + 1),
+            'timestep': slice(2 * n + k + 1, 2 * n + k + 2)}
+
+
+def make_observation_space(n: int, k: int, requested_energy_cap: float) -> spaces.Dict:
+    """env.py:143-150."""
+    return spaces.Dict({
+        'timestep': spaces.Box(0, 1, shape=(1,), dtype=np.float32),
+        'est_departures': spaces.Box(-288, 288, shape=(n,), dtype=np.float32),
+        'demands': spaces.Box(0, requested_energy_cap, shape=(n,), dtype=np.float32),
+        'prev_moer': spaces.Box(0, 1, shape=(1,), dtype=np.float32),
+        'forecasted_moer': spaces.Box(0, 1, shape=(k,), dtype=np.float32),
+    })
+
+
+def _pad_table(table: EventTable, stride: int):
+    from ._lib import SESSION_DTYPE
+    if len(table) > stride:
+        raise ValueError(f'episode has {len(table)} sessions, engine capacity is {stride}')
+    s = np.zeros(stride, dtype=SESSION_DTYPE)
+    r = np.zeros(stride, dtype=np.float64)
+    s[:len(table)] = table.sessions
+    r[:len(table)] = table.requested
+    return s, r
+
+
+class EVChargingEnv(_EnvBase):
+    """Single-agent EV charging environment (reference: env.py:20-470), one environment on the
+    GPU engine.  See the reference class docstring for the MDP; constants below are env.py:99-114."""
+    TIMESTEP_DURATION = 5
+    ACTION_SCALE_FACTOR = 32
+    VOLTAGE = 208
+    MARGINAL_REVENUE_PER_KWH = 0.15
+    OPERATING_MARGIN = 0.20
+    MARGINAL_PROFIT_PER_KWH = MARGINAL_REVENUE_PER_KWH * OPERATING_MARGIN
+    CO2_COST_PER_METRIC_TON = 30.85
+    A_MINS_TO_KWH = (1 / 60) * (VOLTAGE / 1000)
+    VIOLATION_WEIGHT = 0.001
+    A_PERS_TO_KWH = A_MINS_TO_KWH * TIMESTEP_DURATION
+    PROFIT_FACTOR = A_PERS_TO_KWH * MARGINAL_PROFIT_PER_KWH
+    VIOLATION_FACTOR = A_PERS_TO_KWH * VIOLATION_WEIGHT
+    CARBON_COST_FACTOR = A_PERS_TO_KWH * (CO2_COST_PER_METRIC_TON / 1000)
+
+    metadata: dict[str, Any] = {}
+    render_mode = None
+
+    def __init__(self, data_generator: AbstractTraceGenerator, moer_forecast_steps: int = 36,
+                 project_action_in_env: bool = True, verbose: int = 0, device: int = 0):
+        assert 1 <= moer_forecast_steps <= 36                                   # env.py:120
+        self.data_generator = data_generator
+        self.max_timestep = 288                                                  # env.py:124
+        self.moer_forecast_steps = moer_forecast_steps
+        self.project_action_in_env = project_action_in_env
+        self.verbose = verbose
+        self.cn = site_str_to_site(data_generator.site)                          # env.py:132
+        self.num_stations = len(self.cn.station_ids)
+        n, k = self.num_stations, moer_forecast_steps
+        self.observation_space = make_observation_space(n, k, data_generator.requested_energy_cap)
+        self.action_space = spaces.Box(low=0, high=1.0, shape=(n,), dtype=np.float32)  # env.py:171
+        self._engine = StepEngine(self.cn, 1, moer_forecast_steps=k, project_action=project_action_in_env,
+                                  autoreset=False, device=device, bank_slots=1,
+                                  max_sessions=MAX_SESSIONS, moer_days=1, debug_outputs=True)
+        self._flat = np.zeros(2 * n + k + 2, dtype=np.float32)
+        sl = obs_slices(n, k)
+        # like the reference (env.py:152-158) the observation arrays are reused buffers
+        self._obs = {key: self._flat[sl[key]] for key in
+                     ('timestep', 'est_departures', 'demands', 'prev_moer', 'forecasted_moer')}
+        self._reward_breakdown = {'profit': 0.0, 'carbon_cost': 0.0, 'excess_charge': 0.0}
+        self._max_profit = 0.0
+        self._evs: EventTable | None = None
+        self._pilots = np.zeros((289, n))
+        self.moer: np.ndarray | None = None
+        self.t = 0
+        self._needs_reset = True
+
+    def __repr__(self) -> str:
+        return (f'EVChargingGym (action projection = {self.project_action_in_env}, '
+                f'moer forecast steps = {self.moer_forecast_steps}) '
+                f'using {self.data_generator.__repr__()}')
+
+    # -- reference API --------------------------------------------------------------------
+    def reset(self, *, seed: int | None = None, options: dict[str, Any] | None = None):
+        """env.py:293-338."""
+        if _gym is not None:  # pragma: no cover
+            super().reset(seed=seed)
+        self.data_generator.set_seed(seed)                                       # env.py:314
+        if options is not None and 'verbose' in options:
+            self.verbose = options['verbose']
+        table = self.data_generator.get_event_table()                            # env.py:321
+        self._evs = table
+        self._max_profit = table.max_profit()                                    # env.py:322
+        self.moer = self.data_generator.get_moer()                               # env.py:323 (advanced day)
+        s, r = _pad_table(table, MAX_SESSIONS)
+        self._engine.upload_moer(self.moer[None], 0)
+        self._engine.upload_episodes([len(table)], s[None], r[None], [0], 0)
+        obs = self._engine.reset(host=True)
+        self._flat[:] = obs[0]
+        self.t = 0
+        for key in self._reward_breakdown:
+            self._reward_breakdown[key] = 0.0
+        self._pilots[:] = 0
+        self._needs_reset = False
+        if self.verbose >= 1:
+            print(f'Simulating {len(table)} events using {self.data_generator}')
+        return self._obs, self._get_info()
+
+    def step(self, action: np.ndarray):
+        """env.py:229-291."""
+        if self._needs_reset:
+            raise RuntimeError('call reset() before step()')      # reference: AttributeError on _simulator
+        action = np.asarray(action)
+        if np.issubdtype(action.dtype, np.integer):
+            raise TypeError('integer actions need DiscreteActionWrapper')
+        out = self._engine.step(np.ascontiguousarray(action, dtype=np.float32).reshape(1, -1))
+        self.t += 1
+        self._flat[:] = out['obs'][0]
+        reward = float(out['reward'][0])
+        done = bool(out['terminated'][0])
+        bd = out['breakdown'][0]
+        self._reward_breakdown['profit'] = float(bd[0])
+        self._reward_breakdown['carbon_cost'] = float(bd[1])
+        self._reward_breakdown['excess_charge'] = float(bd[2])
+        self._pilots[self.t - 1] = out['pilots'][0]
+        self._last = out
+        if done:
+            self._needs_reset = True
+        return self._obs, reward, done, False, self._get_info()
+
+    def _get_info(self, all: bool = False) -> dict[str, Any]:                   # env.py:396-416
+        info = {'max_profit': self._max_profit, 'reward_breakdown': self._reward_breakdown}
+        if all:
+            info.update({'num_evs': len(self._evs), 'avg_plugin_time': self._evs.avg_plugin_time(),
+                         'evs': self._evs, 'moer': self.moer,
+                         'pilot_signals': self._pilots[:self.t].copy(),
+                         'status': int(self._engine.env_scalars()['status'][0])})
+        return info
+
+    def close(self) -> None:                                                     # env.py:466-470
+        if getattr(self, '_engine', None) is not None:
+            self._engine.close()
+            self._engine = None
+
+    def render(self) -> None:
+        return None
+
+
+class DiscreteActionWrapper:
+    """wrappers.py:13-45: discrete {0..bins-1}^n actions -> a/(bins-1).  The float32 division
+    itself runs in the engine (EVC_ACTION_DISCRETE)."""
+
+    def __init__(self, env: EVChargingEnv, bins: int = 5):
+        if not isinstance(env.action_space, spaces.Box):
+            raise ValueError('Should only be used to wrap continuous env')      # wrappers.py:28
+        self.env = env
+        self._bins = bins
+        dims = env.action_space.shape
+        self.action_space = (spaces.Discrete(bins) if len(dims) == 0 else
+                             spaces.MultiDiscrete(np.ones(dims, dtype=np.int64) * bins))
+        self.observation_space = env.observation_space
+
+    def __repr__(self) -> str:
+        return repr(self.env)
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def action(self, action):                                                    # wrappers.py:43-45
+        return np.asarray(action, dtype=np.float32) / (self._bins - 1)
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def step(self, action):
+        return self.env.step(self.action(action))
+
+    def close(self):
+        return self.env.close()
+
+
+class MultiAgentEVChargingEnv:
+    """multiagent_env.py:18-218 (PettingZoo ``ParallelEnv`` protocol, one agent per EVSE).
+
+    ``periods_delay`` > 0: the reference implementation stores aliases of reused buffers, so its
+    delayed observations equal the current ones.  The default
+    ``delay_semantics='reference'`` reproduces that; ``'documented'`` implements the documented
+    behaviour (own information current, other agents' ``periods_delay`` steps old)."""
+    metadata: dict[str, Any] = {}
+
+    def __init__(self, data_generator: AbstractTraceGenerator, periods_delay: int = 0,
+                 moer_forecast_steps: int = 36, project_action_in_env: bool = True,
+                 discrete_bins: int = -1, verbose: int = 0, delay_semantics: str = 'reference',
+                 device: int = 0):
+        assert delay_semantics in ('reference', 'documented')
+        self.periods_delay = periods_delay
+        self.delay_semantics = delay_semantics
+        base = EVChargingEnv(data_generator, moer_forecast_steps, project_action_in_env, verbose, device)
+        self._base = base
+        self.single_env = base if discrete_bins <= 0 else DiscreteActionWrapper(base, bins=discrete_bins)
+        self.agents = base.cn.station_ids[:]
+        self.possible_agents = self.agents
+        flat_space = spaces.flatten_space(base.observation_space)                # :88
+        self.observation_spaces = {a: flat_space for a in self.agents}
+        act = spaces.Discrete(discrete_bins) if discrete_bins > 0 else spaces.Box(0., 1., shape=(1,))
+        self.action_spaces = {a: act for a in self.agents}
+        self._discrete = discrete_bins > 0
+        self._past: list[np.ndarray] = []
+
+    @property
+    def num_agents(self) -> int:
+        return len(self.agents)
+
+    @property
+    def max_num_agents(self) -> int:
+        return len(self.possible_agents)
+
+    def _obs_dict(self, init: bool = False) -> dict[str, np.ndarray]:
+        flat = self._base._flat.copy()                  # spaces.flatten(...) of the Dict obs (:115)
+        if self.periods_delay == 0 or self.delay_semantics == 'reference':
+            return {a: flat for a in self.agents}
+        n = self._base.num_stations
+        if init:
+            self._past = [flat.copy() for _ in range(self.periods_delay)]
+            return {a: flat for a in self.agents}
+        old = self._past.pop(0)
+        self._past.append(flat.copy())
+        out = {}
+        for i, a in enumerate(self.agents):
+            o = flat.copy()
+            o[:2 * n] = old[:2 * n]                     # others: delayed demands / est_departures
+            o[i], o[n + i] = flat[i], flat[n + i]       # own: current
+            out[a] = o
+        return out
+
+    def step(self, actions: dict[str, np.ndarray]):
+        """multiagent_env.py:157-195."""
+        dtype = np.int64 if self._discrete else np.float32
+        action = np.zeros(len(self.agents), dtype=dtype)
+        for i, a in enumerate(self.agents):
+            action[i] = np.asarray(actions[a]).reshape(-1)[0] if not np.isscalar(actions[a]) else actions[a]
+        obs, reward, terminated, truncated, info = self.single_env.step(action)
+        obss = self._obs_dict()
+        n_agents = self.num_agents
+        rewards = {a: float(reward) / n_agents for a in self.agents}            # :186
+        terminateds = {a: terminated for a in self.agents}
+        truncateds = {a: truncated for a in self.agents}
+        infos = {a: info for a in self.agents}
+        if terminated or truncated:
+            self.agents = []                                                     # :192-193
+        return obss, rewards, terminateds, truncateds, infos
+
+    def reset(self, seed: int | None = None, options: dict | None = None):
+        _, info = self.single_env.reset(seed=seed, options=options)
+        self.agents = self.possible_agents[:]
+        return self._obs_dict(init=True), {a: info for a in self.agents}
+
+    def render(self) -> None:
+        return None
+
+    def close(self) -> None:
+        self.single_env.close()
+
+    def observation_space(self, agent: str):
+        return self.observation_spaces[agent]
+
+    def action_space(self, agent: str):
+        return self.action_spaces[agent]
+
+
+class EVChargingVectorEnv:
+    """N independent EVChargingEnv instances stepped by one engine call (Gymnasium 0.28
+    ``VectorEnv`` semantics: batched dict observation, autoreset, ``final_observation``).
+
+    ``data_generators``: a list of N generators or a factory ``i -> generator`` (like the
+    ``env_fns`` of SB3's SubprocVecEnv, train_stable_baselines.py:271-275).  All generators must
+    cover the same site and date period (the period's MOER days are uploaded once).  Episodes are
+    double-buffered in the engine's bank: while environment i plays the episode in slot i the next
+    one already sits in slot i+N, and the kernel-side autoreset flips between the two.
+
+    ``output='numpy'`` (default) returns host arrays (SB3 / RLLib); ``'torch'`` takes and returns
+    device tensors without leaving the GPU."""
+
+    def __init__(self, data_generators: Sequence[AbstractTraceGenerator] | Callable[[int], AbstractTraceGenerator],
+                 num_envs: int | None = None, moer_forecast_steps: int = 36,
+                 project_action_in_env: bool = True, discrete_bins: int = -1, device: int = 0,
+                 output: str = 'numpy', max_sessions: int = 128):
+        assert output in ('numpy', 'torch')
+        if callable(data_generators):
+            assert num_envs is not None
+            gens = [data_generators(i) for i in range(num_envs)]
+        else:
+            gens = list(data_generators)
+        self.generators = gens
+        self.num_envs = N = len(gens)
+        g0 = gens[0]
+        assert all(g.site == g0.site and g.date_range_str == g0.date_range_str for g in gens), \
+            'all generators must share site and date period'
+        self.cn = site_str_to_site(g0.site)
+        self.num_stations = n = self.cn.num_stations
+        self.moer_forecast_steps = k = moer_forecast_steps
+        self.project_action_in_env = project_action_in_env
+        self.discrete_bins = discrete_bins
+        self.output = output
+        self._stride = max_sessions
+        self.single_observation_space = make_observation_space(n, k, g0.requested_energy_cap)
+        self.single_action_space = (spaces.MultiDiscrete(np.full(n, discrete_bins, np.int64))
+                                    if discrete_bins > 0 else
+                                    spaces.Box(low=0, high=1.0, shape=(n,), dtype=np.float32))
+        self.observation_space = self.single_observation_space
+        self.action_space = self.single_action_space
+        self._ndays = g0.num_days_in_date_range
+        self._day0 = g0.date_range[0]
+        self._engine = StepEngine(self.cn, N, moer_forecast_steps=k, project_action=project_action_in_env,
+                                  autoreset=True, device=device, bank_slots=2 * N,
+                                  max_sessions=max_sessions, moer_days=self._ndays)
+        from datetime import timedelta
+        moer = np.stack([g0.moer_loader.retrieve(self._day0 + timedelta(days=d)) for d in range(self._ndays)])
+        self._engine.upload_moer(moer, 0)
+        self._engine.set_autoreset_stride(N)
+        self._slices = obs_slices(n, k)
+        self._max_profit = np.zeros(2 * N)            # per bank slot
+        self._cur_slot = np.arange(N)                 # slot each env is playing
+        self._episodes = np.zeros(N, dtype=np.int64)
+        self.closed = False
+
+    # -- episode staging ------------------------------------------------------------------
+    def _stage(self, env_ids: np.ndarray, slots: np.ndarray, seeds) -> None:
+        from ._lib import SESSION_DTYPE
+        cnt = len(env_ids)
+        ns = np.zeros(cnt, np.int32)
+        sess = np.zeros((cnt, self._stride), dtype=SESSION_DTYPE)
+        req = np.zeros((cnt, self._stride))
+        day = np.zeros(cnt, np.int32)
+        for j, (i, seed) in enumerate(zip(env_ids, seeds)):
+            g = self.generators[i]
+            g.set_seed(seed)                           # env.py:314 (also on autoreset: reset() -> seed=None)
+            table = g.get_event_table()
+            ns[j] = len(table)
+            sess[j], req[j] = _pad_table(table, self._stride)
+            day[j] = (g.day - self._day0).days         # MOER of the advanced day (env.py:321-323)
+            self._max_profit[slots[j]] = table.max_profit()
+        order = np.argsort(slots)
+        # contiguous runs of slots upload in one call each
+        s_sorted = slots[order]
+        start = 0
+        for end in range(1, cnt + 1):
+            if end == cnt or s_sorted[end] != s_sorted[end - 1] + 1:
+                sel = order[start:end]
+                self._engine.upload_episodes(ns[sel], sess[sel], req[sel], day[sel], int(s_sorted[start]))
+                start = end
+
+    def _wrap_obs(self, flat):
+        return {key: flat[:, sl] for key, sl in self._slices.items()}
+
+    # -- VectorEnv API --------------------------------------------------------------------
+    def reset(self, *, seed: int | Sequence[int] | None = None, options: dict | None = None):
+        N = self.num_envs
+        if seed is None:
+            seeds = [None] * N
+        elif np.isscalar(seed):
+            seeds = [int(seed) + i for i in range(N)]  # gymnasium VectorEnv seeding convention
+        else:
+            seeds = list(seed)
+        ids = np.arange(N)
+        self._stage(ids, ids, seeds)                  # current episodes -> slots [0, N)
+        self._stage(ids, ids + N, [None] * N)         # next episodes   -> slots [N, 2N)
+        self._cur_slot = ids.copy()
+        host = self.output == 'numpy'
+        obs = self._engine.reset(slots=ids, host=host)
+        if host:
+            obs = obs.copy()
+        return self._wrap_obs(obs), self._infos(None, None)
+
+    def _infos(self, out, done_mask):
+        bd = None if out is None else out['breakdown']
+        info = {'max_profit': self._max_profit[self._cur_slot].copy()}
+        if bd is not None:
+            info['reward_breakdown'] = {'profit': bd[:, 0], 'carbon_cost': bd[:, 1], 'excess_charge': bd[:, 2]}
+        if done_mask is not None and done_mask.any():
+            info['final_observation'] = self._wrap_obs(out['final_obs'])
+            info['_final_observation'] = done_mask
+            info['final_info'] = {'max_profit': self._final_max_profit}
+            info['_final_info'] = done_mask
+        return info
+
+    def step(self, actions):
+        N = self.num_envs
+        bins = self.discrete_bins if self.discrete_bins > 0 else 0
+        if self.output == 'numpy':
+            out = self._engine.step(np.ascontiguousarray(actions), bins=bins)
+            term = out['terminated'].astype(bool)
+            out = {k: (v.copy() if k in ('obs', 'reward', 'breakdown') or (k == 'final_obs' and term.any()) else v)
+                   for k, v in out.items()}
+        else:
+            out = self._engine.step(actions, bins=bins)
+            term = out['terminated'].bool()
+        done_mask = term.cpu().numpy() if hasattr(term, 'cpu') else term
+        self._final_max_profit = self._max_profit[self._cur_slot].copy()
+        if done_mask.any():
+            ids = np.nonzero(done_mask)[0]
+            vacated = self._cur_slot[ids].copy()
+            self._cur_slot[ids] = (vacated + N) % (2 * N)     # kernel autoreset: slot + stride
+            self._episodes[ids] += 1
+            self._stage(ids, vacated, [None] * len(ids))      # refill the vacated slots
+        truncated = np.zeros(N, dtype=bool) if self.output == 'numpy' else term.new_zeros(N)
+        return self._wrap_obs(out['obs']), out['reward'], term, truncated, self._infos(out, done_mask)
+
+    def close(self) -> None:
+        if not self.closed:
+            self._engine.close()
+            self.closed = True
+
+    # -- multi-agent view (config 5): every agent sees the same flattened observation -----
+    def agent_observations(self, flat_obs):
+        """``[N, F] -> [N, n_agents, F]`` zero-copy broadcast view (multiagent_env.py:114-117 hands
+        the same array object to every agent)."""
+        n = self.num_stations
+        if hasattr(flat_obs, 'expand'):
+            return flat_obs.unsqueeze(1).expand(-1, n, -1)
+        return np.broadcast_to(flat_obs[:, None, :], (flat_obs.shape[0], n, flat_obs.shape[1]))
+
+
+class SB3VecEnv:
+    """stable_baselines3 ``VecEnv`` protocol over :class:`EVChargingVectorEnv`
+    (used like train_stable_baselines.py:275 uses SubprocVecEnv; policy ``MultiInputPolicy``)."""
+
+    def __init__(self, venv: EVChargingVectorEnv):
+        assert venv.output == 'numpy'
+        self.venv = venv
+        self.num_envs = venv.num_envs
+        self.observation_space = venv.single_observation_space
+        self.action_space = venv.single_action_space
+        self.render_mode = None
+        self._actions = None
+        self._seeds: list[int | None] = [None] * self.num_envs
+
+    def seed(self, seed: int | None = None):
+        self._seeds = [None if seed is None else seed + i for i in range(self.num_envs)]
+        return self._seeds
+
+    def reset(self):
+        seeds = None if all(s is None for s in self._seeds) else self._seeds
+        obs, _ = self.venv.reset(seed=seeds)
+        self._seeds = [None] * self.num_envs
+        return {k: v.copy() for k, v in obs.items()}
+
+    def step_async(self, actions) -> None:
+        self._actions = actions
+
+    def step_wait(self):
+        obs, rew, term, trunc, info = self.venv.step(self._actions)
+        infos: list[dict[str, Any]] = []
+        bd = info['reward_breakdown']
+        for i in range(self.num_envs):
+            d = {'max_profit': float(info['max_profit'][i]),
+                 'reward_breakdown': {k: float(v[i]) for k, v in bd.items()},
+                 'TimeLimit.truncated': False}
+            if term[i]:
+                d['terminal_observation'] = {k: v[i].copy() for k, v in info['final_observation'].items()}
+            infos.append(d)
+        return {k: v.copy() for k, v in obs.items()}, rew.astype(np.float32), term, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self) -> None:
+        self.venv.close()
+
+    def get_attr(self, attr_name, indices=None):
+        idx = range(self.num_envs) if indices is None else indices
+        return [getattr(self.venv, attr_name) for _ in idx]
+
+    def set_attr(self, attr_name, value, indices=None) -> None:
+        setattr(self.venv, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        idx = range(self.num_envs) if indices is None else indices
+        return [getattr(self.venv, method_name)(*args, **kwargs) for _ in idx]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        idx = range(self.num_envs) if indices is None else indices
+        return [False for _ in idx]
+
+    def get_images(self):
+        return [None] * self.num_envs

@@ -1,0 +1,182 @@
+"""Drop-in API layer on the GPU: the conformance properties the reference's own tests assert
+(tests/test_evcharging.py: gymnasium check_env / PettingZoo parallel_api_test: spaces, dtypes,
+determinism on seed, 288-step episodes, agents == [] after termination) plus parity of the
+single-env API against the oracle on REAL trace days."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from sustaingym_amd import (DiscreteActionWrapper, EVChargingEnv, EVChargingVectorEnv,
+                            GMMsTraceGenerator, MultiAgentEVChargingEnv, RealTraceGenerator, SB3VecEnv)
+from sustaingym_amd.envs import obs_slices
+
+pytestmark = pytest.mark.gpu
+
+
+def in_space(space, obs):
+    for key, sp in space.spaces.items():
+        a = obs[key]
+        assert a.dtype == np.float32 and a.shape == sp.shape, key
+        assert np.all(a >= sp.low) and np.all(a <= sp.high), key
+
+
+def test_single_env_conformance_and_determinism():
+    env = EVChargingEnv(RealTraceGenerator('caltech', 'Summer 2021'))
+    rng = np.random.default_rng(0)
+    traj = []
+    for rep in range(2):
+        obs, info = env.reset(seed=7)
+        in_space(env.observation_space, obs)
+        assert set(info) == {'max_profit', 'reward_breakdown'}
+        assert obs['timestep'][0] == 0 and not obs['demands'].any()
+        rng = np.random.default_rng(1)
+        rews = []
+        for t in range(288):
+            a = env.action_space.sample() if rep < 0 else rng.random(54, dtype=np.float32)
+            obs, r, term, trunc, info = env.step(a)
+            in_space(env.observation_space, obs)
+            assert isinstance(r, float) and trunc is False
+            assert term == (t == 287)
+            rews.append(r)
+        traj.append((np.array(rews), dict(info['reward_breakdown']), info['max_profit']))
+        with pytest.raises(RuntimeError):
+            env.step(a)
+    assert np.array_equal(traj[0][0], traj[1][0]) and traj[0][1] == traj[1][1]
+    assert abs(sum(traj[0][0]) - (traj[0][1]['profit'] - traj[0][1]['carbon_cost'] - traj[0][1]['excess_charge'])) < 1e-9
+    env.close()
+
+
+@pytest.mark.parametrize('site,period,seed', [('caltech', 'Spring 2020', 2), ('caltech', 'Summer 2019', 40),
+                                               ('jpl', 'Fall 2019', 3)])
+@pytest.mark.parametrize('project', [True, False])
+def test_single_env_real_trace_matches_oracle(site, period, seed, project):
+    """EVChargingEnv on a real ACN-Data day vs the CPU oracle fed with the same event table."""
+    gen = RealTraceGenerator(site, period)
+    env = EVChargingEnv(gen, project_action_in_env=project)
+    obs, info = env.reset(seed=seed)
+    table, moer = env._evs, env.moer
+    onet = ob.OracleNetwork(env.cn)
+    orc = ob.OracleEnv(onet, 36, project)
+    o_obs = orc.reset(table.sessions, table.requested, moer)
+    n = env.num_stations
+    sl = obs_slices(n, 36)
+    assert abs(info['max_profit'] - ob.max_profit(table.sessions, table.requested)) < 1e-12
+    rng = np.random.default_rng(seed)
+    for t in range(288):
+        a = rng.random(n, dtype=np.float32) if t % 5 else np.ones(n, np.float32)
+        obs, r, term, _, info = env.step(a.copy())
+        o_obs, res = orc.step(a)
+        assert np.array_equal(env._last['pilots'][0], np.array(res.pilots[:n])), t
+        assert np.array_equal(obs['est_departures'], o_obs[sl['est_departures']])
+        assert np.array_equal(obs['forecasted_moer'], o_obs[sl['forecasted_moer']])
+        assert obs['prev_moer'][0] == o_obs[sl['prev_moer']][0] and obs['timestep'][0] == o_obs[sl['timestep']][0]
+        np.testing.assert_allclose(obs['demands'], o_obs[sl['demands']], rtol=2e-7)
+        assert abs(r - res.reward) <= 1e-9 * max(1e-3, abs(res.reward))
+        assert term == bool(res.terminated)
+    for key, v in zip(('profit', 'carbon_cost', 'excess_charge'), res.breakdown):
+        assert abs(info['reward_breakdown'][key] - v) <= 1e-9 * max(1.0, abs(v))
+    env.close()
+
+
+def test_discrete_wrapper():
+    env = DiscreteActionWrapper(EVChargingEnv(RealTraceGenerator('caltech', 'Summer 2021'),
+                                              project_action_in_env=False), bins=5)
+    assert env.action_space.nvec.tolist() == [5] * 54
+    env.reset(seed=1)
+    obs, r, term, trunc, info = env.step(np.full(54, 4, dtype=np.int64))
+    assert np.array_equal(env.env._last['pilots'][0], np.full(54, 32.0))
+    obs, r, term, trunc, info = env.step(np.arange(54) % 5)
+    exp = [(8.0 * (i % 5)) for i in range(54)]
+    assert env.env._last['pilots'][0].tolist() == exp       # {0,8,16,24,32} legal for AV and CC
+    env.close()
+
+
+def test_multiagent_parallel_api():
+    env = MultiAgentEVChargingEnv(GMMsTraceGenerator('caltech', 'Summer 2019'), discrete_bins=-1)
+    single = EVChargingEnv(GMMsTraceGenerator('caltech', 'Summer 2019'))
+    obss, infos = env.reset(seed=123)
+    s_obs, _ = single.reset(seed=123)
+    assert env.agents == env.possible_agents and len(env.agents) == 54
+    assert env.observation_space(env.agents[0]).shape == (146,)
+    assert env.action_space(env.agents[0]).shape == (1,)
+    rng = np.random.default_rng(0)
+    for t in range(288):
+        acts = {a: rng.random(1, dtype=np.float32) for a in env.agents}
+        vec = np.array([acts[a][0] for a in env.agents], dtype=np.float32)
+        obss, rews, terms, truncs, infos = env.step(acts)
+        s_obs, s_r, s_term, _, _ = single.step(vec)
+        first = obss[env.possible_agents[0]]
+        assert first.shape == (146,) and first.dtype == np.float32
+        assert all(o is first for o in obss.values())                      # same array for every agent
+        assert np.array_equal(first, single._flat)                          # flatten(Dict) key order
+        assert all(abs(r - s_r / 54) < 1e-15 for r in rews.values())
+        assert all(v == (t == 287) for v in terms.values()) and not any(truncs.values())
+    assert env.agents == []
+    # seed determinism (PettingZoo parallel_seed_test)
+    o1, _ = env.reset(seed=5)
+    o2, _ = env.reset(seed=5)
+    assert np.array_equal(o1[env.agents[0]], o2[env.agents[0]])
+    env.close()
+    single.close()
+
+
+def test_multiagent_documented_delay():
+    env = MultiAgentEVChargingEnv(GMMsTraceGenerator('caltech', 'Summer 2019'), periods_delay=3,
+                                  delay_semantics='documented', project_action_in_env=False)
+    env.reset(seed=11)
+    hist = []
+    for t in range(150):
+        obss, *_ = env.step({a: np.ones(1, np.float32) for a in env.agents})
+        hist.append(env._base._flat.copy())
+        if t >= 3:
+            a0, i0 = env.agents[0], 0
+            o = obss[a0]
+            assert o[i0] == hist[t][i0]                                   # own demand: current
+            assert np.array_equal(o[1:54], hist[t - 3][1:54])              # others: 3 periods old
+            assert np.array_equal(o[108:], hist[t][108:])                  # moer / timestep: current
+    env.close()
+
+
+def test_vector_env_autoreset_and_single_env_equivalence():
+    N = 6
+    venv = EVChargingVectorEnv(lambda i: GMMsTraceGenerator('caltech', 'Summer 2019'), num_envs=N)
+    obs, info = venv.reset(seed=100)
+    singles = [EVChargingEnv(GMMsTraceGenerator('caltech', 'Summer 2019')) for _ in range(N)]
+    s_obs = [e.reset(seed=100 + i)[0] for i, e in enumerate(singles)]
+    for i in range(N):
+        assert np.array_equal(obs['forecasted_moer'][i], s_obs[i]['forecasted_moer'])
+        assert abs(info['max_profit'][i] - singles[i]._max_profit) < 1e-12
+    rng = np.random.default_rng(0)
+    for t in range(288 + 20):
+        a = rng.random((N, 54), dtype=np.float32)
+        obs, rew, term, trunc, info = venv.step(a)
+        assert rew.shape == (N,) and term.shape == (N,) and not trunc.any()
+        if t < 288:
+            for i, e in enumerate(singles):
+                so, sr, st, _, si = e.step(a[i])
+                assert sr == rew[i] and st == term[i]
+                if t < 287:
+                    for key in so:
+                        assert np.array_equal(so[key], obs[key][i]), (key, t)
+                else:
+                    assert info['_final_observation'].all()
+                    for key in so:
+                        assert np.array_equal(so[key], info['final_observation'][key][i]), key
+                    assert obs['timestep'][i, 0] == 0                      # first obs of next episode
+                    assert abs(info['final_info']['max_profit'][i] - e._max_profit) < 1e-12
+        else:
+            assert obs['timestep'][0, 0] == np.float32((t - 287) / 288)
+    # SB3 VecEnv protocol
+    sb3 = SB3VecEnv(venv)
+    sb3.seed(3)
+    o = sb3.reset()
+    assert o['demands'].shape == (N, 54)
+    for t in range(288):
+        o, r, d, infos = sb3.step(rng.random((N, 54), dtype=np.float32))
+    assert d.all() and 'terminal_observation' in infos[0] and r.dtype == np.float32
+    assert infos[0]['terminal_observation']['timestep'][0] == 1.0
+    av = venv.agent_observations(np.zeros((N, 146), np.float32))
+    assert av.shape == (N, 54, 146) and av.strides[1] == 0
+    venv.close()
+    for e in singles:
+        e.close()
