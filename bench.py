@@ -67,6 +67,7 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
+    from sustaingym_amd.distributed import all_gather_metrics, max_over_ranks, metrics_vector
     from sustaingym_amd.engine import StepEngine
     from sustaingym_amd.network import site_str_to_site
     from sustaingym_amd.synthetic import synthetic_episodes, synthetic_moer
@@ -104,22 +105,10 @@ def main():
     for i in range(args.steps):
         step(ptrs[i % len(ptrs)])
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
 
     # ---- metrics all-gather (the only collective of the path; off the step critical path) ----
-    m = eng.read_metrics()
-    vec = torch.tensor([m['profit'], m['carbon_cost'], m['excess_charge'], m['env_steps'],
-                        m['episodes_finished'], m['envs_with_status']], dtype=torch.float64, device=dev)
-    if dist is not None:
-        gathered = [torch.zeros_like(vec) for _ in range(world)]
-        dist.all_gather(gathered, vec)
-        total = torch.stack(gathered).sum(0).cpu().numpy()
-    else:
-        total = vec.cpu().numpy()
+    _, total = all_gather_metrics(metrics_vector(eng.read_metrics()), dev)
 
     # ---- per-kernel duration with HIP events on the engine's stream (rank 0) ----
     roofline = None
@@ -157,7 +146,6 @@ def main():
         from oracle import binding as ob
         cn, cs = args.cpu_envs, args.cpu_steps
         bat = ob.OracleBatch(ob.OracleNetwork(net), cn, k, project)
-        cns, csess, creq, cday = ns[:cn % P or P], sess, req, day
         bat.set_bank(ns, sess, req, day, moer, autoreset_stride=1)
         bat.reset(np.arange(cn, dtype=np.int32) % P)
         cores = ob.max_threads()

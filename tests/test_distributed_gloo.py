@@ -1,0 +1,72 @@
+"""N>1 path on CPU: world_size-2 gloo ranks shard the environment ids, build their shard's
+episodes with per-environment seeds and all-gather the metrics vector (the only collective of the
+path).  The sharded result must equal the single-process result."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sustaingym_amd.distributed import (METRIC_NAMES, all_gather_metrics, max_over_ranks,
+                                        shard_range, shard_seeds)
+from sustaingym_amd.event_generation import GMMsTraceGenerator
+
+
+def episode_signature(seed: int) -> np.ndarray:
+    g = GMMsTraceGenerator('caltech', 'Summer 2021')
+    g.set_seed(seed)
+    t = g.get_event_table()
+    return np.array([len(t), t.max_profit(), float(t.sessions['arrival'].sum()), 1.0, 0.0, 0.0])
+
+
+def _worker(rank, world, port, global_envs, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    seeds = shard_seeds(1000, rank, world, global_envs)
+    local = np.zeros(len(METRIC_NAMES))
+    for s in seeds:
+        local += episode_signature(s)
+    per_rank, total = all_gather_metrics(local)
+    tmax = max_over_ranks(float(rank + 1))
+    dist.barrier()
+    if rank == 0:
+        q.put((per_rank, total, tmax))
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_partition_everything():
+    for N in (1, 7, 64, 65536):
+        for W in (1, 2, 3, 8):
+            ranges = [shard_range(N, r, W) for r in range(W)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == N
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            sizes = [hi - lo for lo, hi in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_seeds(None, 0, 2, 4) == [None, None]
+    assert shard_seeds(10, 1, 2, 4) == [12, 13]
+
+
+def test_two_gloo_ranks_match_single_process():
+    global_envs, world = 6, 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, global_envs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    per_rank, total, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = sum(episode_signature(1000 + i) for i in range(global_envs))
+    assert per_rank.shape == (2, len(METRIC_NAMES))
+    np.testing.assert_allclose(total, expect, rtol=1e-12)
+    assert total[3] == global_envs and tmax == 2.0
+    # identity without a process group
+    pr, tot = all_gather_metrics(expect)
+    assert np.array_equal(tot, expect) and pr.shape == (1, 6)
