@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libevcharge_hip.so')
+LIB_PATH = os.environ.get('SUSTAINGYM_AMD_LIB', os.path.join(_PKG, 'libevcharge_hip.so'))
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'evcharge.h')
 
 ABI_VERSION = 1

@@ -53,8 +53,21 @@ struct NetTables {
     // reads consecutive addresses; only the [G][m] corner is populated.
     double Mre[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
     double Mim[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
-    double Aabs[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];  // |A[c][rep(g)]|
     double mag[EVC_MAX_CONSTRAINTS];
+    // float32 copies for the conservative (screening) row tests of the streaming kernel
+    float Mre32[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
+    float Mim32[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
+    // screening thresholds (squared, float32, with safety margin):
+    //   thr_y2[c]: class sums are upper bounds in 1/8 A units -> ((r_c - slack_c)(1-1e-4) * 8)^2,
+    //              slack_c = sum_g |A_cg| n_g / 8 covers the quantisation of ceil(8 y)
+    //   thr_p2[c]: pilots are exact integers -> (r_c (1-1e-4))^2
+    float thr_y2[EVC_MAX_CONSTRAINTS];
+    float thr_p2[EVC_MAX_CONSTRAINTS];
+    //   thr_yp2[c]: as thr_y2 but with the slack widened by the worst-case rounding of
+    //              env.py:373-378 (+0.5 A per AV station, +4 A per CC station): if the y screen
+    //              passes THIS threshold the rounded pilots cannot violate row c either
+    float thr_yp2[EVC_MAX_CONSTRAINTS];
+    float timestep[EVC_MOER_ROWS];   // (float)((double)t / 288.0), env.py:392
 };
 
 // Kernel parameters (passed by value; lives in kernarg memory -> scalar loads).
@@ -64,6 +77,11 @@ struct Params {
     int autoreset, autoreset_stride, project;
     unsigned long long group_mask[EVC_MAX_GROUPS];  // lanes of each station class
     unsigned long long cc_mask;                     // lanes with a ClipperCreek EVSE
+    // "simple" rows load a single station class (e.g. the Caltech pod breakers): they cap that
+    // class' sum at magnitude/|coefficient|; +inf if the class has no such row.  Violations of
+    // simple rows only are projected in closed form (water-filling) inside the streaming kernel.
+    double class_cap[EVC_MAX_GROUPS];
+    unsigned simple_rows;                           // bit c set: row c is simple
     // persistent state
     double* rem;             // [N][n] remaining demand (kWh) of the plugged EV
     int* depest;             // [N][n] departure (low 16) | est_departure (high 16)
@@ -125,6 +143,30 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return readlane_f64(wave_scan_f64(v), 63);
 }
 
+// butterfly min over the wave (ds_bpermute; only used on rare paths)
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+
+template <int CTRL, int ROW_MASK, bool BOUND_CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, BOUND_CTRL);
+}
+
+// Wave total of a 32-bit integer (same DPP ladder as wave_scan_f64; 6 fused v_add_u32_dpp).
+// Used with two 16-bit class sums packed per word.
+__device__ __forceinline__ unsigned wave_total_u32(unsigned v) {
+    v += dpp_u32<0x111, 0xf, true>(v);
+    v += dpp_u32<0x112, 0xf, true>(v);
+    v += dpp_u32<0x114, 0xf, true>(v);
+    v += dpp_u32<0x118, 0xf, true>(v);
+    v += dpp_u32<0x142, 0xa, false>(v);
+    v += dpp_u32<0x143, 0xc, false>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Sum over the lanes in `mask` of a value that is an integer in [0, 2^BITS) on every lane:
 // BITS ballots + popcounts, entirely on the scalar unit.
 template <int BITS>
@@ -155,21 +197,19 @@ __device__ __forceinline__ double legal_pilot(double y, bool is_cc) {
 
 // acnportal Linear2StageBattery._charge_stepwise + EV.charge for a battery of capacity 100 kWh,
 // max power 100 kW, whose headroom equals the EV's remaining demand `rem` (event_generation.py
-// :173-176 with requested <= 100).  Returns the actual rate (A) and updates rem.
+// :173-176 with requested <= 100).  Division-free form of the same formulas:
+//   rate_to_full = rem / (5/60) = 12 rem;  bulk stage (soc < 0.8  <=>  rem > 20): P = min(kw, 100, 12 rem)
+//   taper stage: limit = (1-soc)/(1-0.8)*100 = 5 rem  (< 12 rem)  ->  P = min(kw, 5 rem)
+//   amps = P*1000/208;  delivered += (amps*208/1000)*(5/60) = P/12
+// (agrees with the literal operation order of acnportal to a few ulp).
+// `pilot` must already be 0 for lanes without an EV.  Returns the actual rate (A), updates rem.
 __device__ __forceinline__ double charge_ev(double pilot, double& rem) {
-    if (pilot == 0.0) return 0.0;
-    const double period_h = Consts::TIMESTEP_DURATION / 60.0;
-    double rate_to_full = rem / period_h;
-    double soc = (Consts::BATTERY_CAPACITY - rem) / Consts::BATTERY_CAPACITY;
-    double pilot_kw = pilot * Consts::VOLTAGE / 1000.0;
-    double limit = Consts::BATTERY_MAX_POWER;
-    if (!(soc < Consts::TRANSITION_SOC))
-        limit = (1.0 - soc) / (1.0 - Consts::TRANSITION_SOC) * Consts::BATTERY_MAX_POWER;
-    double p = fmin(fmin(pilot_kw, limit), rate_to_full);
-    p = fmin(p, Consts::BATTERY_MAX_POWER);
-    double amps = p * 1000.0 / Consts::VOLTAGE;
-    rem -= (amps * Consts::VOLTAGE / 1000.0) * period_h;
-    return amps;
+    const double kw = pilot * (Consts::VOLTAGE / 1000.0);
+    const double bulk = fmin(12.0 * rem, Consts::BATTERY_MAX_POWER);
+    const double limit = (rem > 20.0) ? bulk : 5.0 * rem;
+    const double p = fmin(kw, limit);
+    rem = rem - p * (1.0 / 12.0);
+    return p * (1000.0 / Consts::VOLTAGE);
 }
 
 }  // namespace evc

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -63,6 +64,7 @@ struct evc_engine {
     int* d_idbuf = nullptr;       // reset ids/slots staging [2N]
     double* d_metrics = nullptr;  // [8]
     // device staging for the *_host entry points
+    float* d_act_f32 = nullptr;   // float32 actions produced by discretize_kernel
     void* d_act = nullptr;        // N*n*8 bytes
     float* d_obs = nullptr;
     double* d_reward = nullptr;
@@ -91,7 +93,7 @@ int bind(evc_engine* e) {
 void free_all(evc_engine* e) {
     void* ptrs[] = {e->d_rem, e->d_depest, e->d_scal, e->d_acc, e->d_sessions, e->d_requested,
                     e->d_nsess, e->d_slot_moer, e->d_moer_hist, e->d_moer_obs, e->d_tables,
-                    e->d_slow_count, e->d_slow_list, e->d_idbuf, e->d_metrics, e->d_act, e->d_obs,
+                    e->d_slow_count, e->d_slow_list, e->d_idbuf, e->d_metrics, e->d_act, e->d_act_f32, e->d_obs,
                     e->d_reward, e->d_term, e->d_breakdown, e->d_final, e->d_pilots, e->d_rates,
                     e->d_proj};
     for (void* p : ptrs)
@@ -133,30 +135,68 @@ int build_tables(const evc_network_desc* net, Params& P, NetTables& T) {
         else if (net->evse_kind[i] != EVC_EVSE_AV)
             return fail(EVC_EINVAL, "evse_kind[%d] = %d is not EVC_EVSE_AV/CC", i, net->evse_kind[i]);
     }
+    for (int t = 0; t < EVC_MOER_ROWS; t++)
+        T.timestep[t] = (float)((double)t / (double)EVC_EPISODE_STEPS);         // env.py:392
+    std::vector<double> slack(m, 0.0), round_slack(m, 0.0);
     for (int g = 0; g < P.G; g++) {
         const int j = rep[g];
         const double rad = net->phase_angles_deg[j] * (M_PI / 180.0);  // np.deg2rad, env.py:485
         const double cs = std::cos(rad), sn = std::sin(rad);
+        const int n_g = __builtin_popcountll(P.group_mask[g]);
         for (int c = 0; c < m; c++) {
             const double a = net->constraint_matrix[c * n + j];
             T.Mre[g][c] = a * cs;
             T.Mim[g][c] = a * sn;
-            T.Aabs[g][c] = std::fabs(a);
+            T.Mre32[g][c] = (float)(a * cs);
+            T.Mim32[g][c] = (float)(a * sn);
+            slack[c] += std::fabs(a) * n_g / 8.0;   // quantisation of ceil(8 y) per station
+            // env.py:373-378 rounding can raise a station by 0.5 A (AV) / 4 A (CC)
+            const int n_cc = __builtin_popcountll(P.group_mask[g] & P.cc_mask);
+            round_slack[c] += std::fabs(a) * (0.5 * (n_g - n_cc) + 4.0 * n_cc);
         }
     }
     for (int c = 0; c < m; c++) {
         if (!(net->magnitudes[c] > 0.0)) return fail(EVC_EINVAL, "magnitudes[%d] must be > 0", c);
-        T.mag[c] = net->magnitudes[c];
+        const double r = net->magnitudes[c];
+        T.mag[c] = r;
+        const double ry = (r - slack[c]) * (1.0 - 1e-4) * 8.0;
+        T.thr_y2[c] = ry > 0.0 ? (float)(ry * ry) : 0.0f;
+        const double rp = r * (1.0 - 1e-4);
+        T.thr_p2[c] = (float)(rp * rp);
+        const double ryp = (r - slack[c] - round_slack[c]) * (1.0 - 1e-4) * 8.0;
+        T.thr_yp2[c] = ryp > 0.0 ? (float)(ryp * ryp) : 0.0f;
+    }
+    // simple rows: all non-zero coefficients inside one station class -> a cap on that class sum
+    P.simple_rows = 0u;
+    for (int g = 0; g < EVC_MAX_GROUPS; g++) P.class_cap[g] = HUGE_VAL;
+    for (int c = 0; c < m; c++) {
+        int cls = -1;
+        bool simple = true;
+        for (int i = 0; i < n && simple; i++) {
+            if (net->constraint_matrix[c * n + i] == 0.0) continue;
+            if (cls < 0) cls = gid[i];
+            else if (cls != gid[i]) simple = false;
+        }
+        if (simple && cls >= 0) {
+            // a class has identical columns, so every member carries the same coefficient
+            const double a = std::fabs(net->constraint_matrix[c * n + rep[cls]]);
+            // the row must load the WHOLE class (true by construction of the classes)
+            P.simple_rows |= 1u << c;
+            const double cap = net->magnitudes[c] / a;
+            if (cap < P.class_cap[cls]) P.class_cap[cls] = cap;
+        }
     }
     return EVC_OK;
 }
 
 void compute_grids(evc_engine* e) {
     int blocks = (e->P.N + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    int cap = 4096;
+    if (const char* s = getenv("EVC_GRID_CAP")) cap = atoi(s) > 0 ? atoi(s) : cap;   // tuning knob
+    if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks -= blocks % 8;
     e->step_grid = blocks;
-    e->solver_grid = e->P.N < 2048 ? e->P.N : 2048;
+    e->solver_grid = e->P.N < 1024 ? e->P.N : 1024;
 }
 
 int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bins,
@@ -169,19 +209,41 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         return fail(EVC_EINVAL, "evc_step: discrete actions need bins >= 2");
     StepIO io;
     io.actions = actions_dev;
-    io.action_kind = action_kind;
-    io.bins = bins;
+    io.action_kind = EVC_ACTION_F32;
+    io.bins = 0;
     io.out = *out;
-    if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
-    if (e->P.project) {
-        HIP_TRY(hipMemsetAsync(e->d_slow_count, 0, sizeof(int), e->stream));
-        hipLaunchKernelGGL(step_kernel<true>, dim3(e->step_grid), dim3(256), 0, e->stream, e->P, io);
-        if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));
-        hipLaunchKernelGGL(solver_step_kernel, dim3(e->solver_grid), dim3(64), 0, e->stream, e->P, io);
-    } else {
-        hipLaunchKernelGGL(step_kernel<false>, dim3(e->step_grid), dim3(256), 0, e->stream, e->P, io);
-        if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+    if (action_kind == EVC_ACTION_DISCRETE) {
+        const size_t count = (size_t)e->P.N * e->P.n;
+        if (!e->d_act_f32) HIP_TRY(dmalloc(&e->d_act_f32, count));
+        int blocks = (int)((count + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(discretize_kernel, dim3(blocks), dim3(256), 0, e->stream,
+                           (const long long*)actions_dev, e->d_act_f32, count, bins);
+        io.actions = e->d_act_f32;
     }
+    if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+    if (e->P.project) HIP_TRY(hipMemsetAsync(e->d_slow_count, 0, sizeof(int), e->stream));
+    const int words = (e->P.G + 1) / 2;
+#define EVC_LAUNCH(W)                                                                              \
+    case W:                                                                                        \
+        if (e->P.project) {                                                                        \
+            hipLaunchKernelGGL((step_kernel<true, W>), dim3(e->step_grid), dim3(256), 0, e->stream, \
+                               e->P, io);                                                          \
+            if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
+            hipLaunchKernelGGL((solver_step_kernel<W>), dim3(e->solver_grid), dim3(64), 0,         \
+                               e->stream, e->P, io);                                               \
+        } else {                                                                                   \
+            hipLaunchKernelGGL((step_kernel<false, W>), dim3(e->step_grid), dim3(256), 0,          \
+                               e->stream, e->P, io);                                               \
+            if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
+        }                                                                                          \
+        break;
+    switch (words) {
+        EVC_LAUNCH(1) EVC_LAUNCH(2) EVC_LAUNCH(3) EVC_LAUNCH(4)
+        EVC_LAUNCH(5) EVC_LAUNCH(6) EVC_LAUNCH(7) EVC_LAUNCH(8)
+        default: return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
+    }
+#undef EVC_LAUNCH
     if (e->timing) {
         HIP_TRY(hipEventRecord(e->ev[2], e->stream));
         e->ev_valid = true;

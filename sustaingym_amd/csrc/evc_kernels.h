@@ -1,4 +1,11 @@
-// evc_kernels.h — the step / reset / projection kernels (gfx950, wave-per-environment).
+// evc_kernels.h — the step / reset kernels (gfx950, wave-per-environment).
+//
+// Instruction budget: at the HBM roofline one environment-step may cost ~230 issue cycles per CU
+// (65 536 envs, 151 MB, 8 TB/s, 256 CUs), so the streaming kernel is written for instruction
+// count: no fp64 divides, class sums as two 16-bit fields per 32-bit DPP scan (6 fused
+// v_add_u32_dpp per word), constraint rows screened in float32 with a safety margin and
+// re-evaluated in float64 only when the screen is inconclusive, nothing on the (single per CU)
+// scalar unit that can live on the four SIMDs.
 #pragma once
 
 #include "evc_device.h"
@@ -9,20 +16,53 @@ namespace evc {
 struct LdsNet {
     double Mre[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
     double Mim[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
-    double Aabs[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
     double mag[EVC_MAX_CONSTRAINTS];
+    float Mre32[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
+    float Mim32[EVC_MAX_GROUPS][EVC_MAX_CONSTRAINTS];
+    float thr_y2[EVC_MAX_CONSTRAINTS];
+    float thr_p2[EVC_MAX_CONSTRAINTS];
+    float thr_yp2[EVC_MAX_CONSTRAINTS];
 };
 
 __device__ __forceinline__ void stage_net(LdsNet& s, const Params& P) {
-    const int m = P.m, G = P.G;
-    for (int idx = threadIdx.x; idx < G * m; idx += blockDim.x) {
+    const int m = P.m;
+    // classes are padded to an even count (two per packed word); padded entries are zero
+    const int Gp = (P.G + 1) & ~1;
+    for (int idx = threadIdx.x; idx < Gp * m; idx += blockDim.x) {
         int g = idx / m, c = idx - g * m;
         s.Mre[g][c] = P.tables->Mre[g][c];
         s.Mim[g][c] = P.tables->Mim[g][c];
-        s.Aabs[g][c] = P.tables->Aabs[g][c];
+        s.Mre32[g][c] = P.tables->Mre32[g][c];
+        s.Mim32[g][c] = P.tables->Mim32[g][c];
     }
-    for (int c = threadIdx.x; c < m; c += blockDim.x) s.mag[c] = P.tables->mag[c];
+    for (int c = threadIdx.x; c < m; c += blockDim.x) {
+        s.mag[c] = P.tables->mag[c];
+        s.thr_y2[c] = P.tables->thr_y2[c];
+        s.thr_p2[c] = P.tables->thr_p2[c];
+        s.thr_yp2[c] = P.tables->thr_yp2[c];
+    }
     __syncthreads();
+}
+
+// Per-lane constants of the network (computed once per wave).
+struct LaneNet {
+    int gid;          // station class of this lane, -1 outside the network
+    int word;         // packed word holding this class' sum (gid >> 1)
+    int shift;        // 0 or 16
+    bool is_cc;
+    bool in_net;
+};
+
+__device__ __forceinline__ LaneNet lane_net(const Params& P, int lane) {
+    LaneNet ln;
+    ln.in_net = lane < P.n;
+    ln.gid = -1;
+    for (int g = 0; g < P.G; g++)
+        if ((P.group_mask[g] >> lane) & 1ull) ln.gid = g;
+    ln.word = ln.gid >> 1;
+    ln.shift = (ln.gid & 1) << 4;
+    ln.is_cc = (P.cc_mask >> lane) & 1ull;
+    return ln;
 }
 
 // Per-lane / per-wave state of the environment a wave is stepping.
@@ -35,24 +75,74 @@ struct EnvRegs {
     int t, cursor, slot, moer_day, n_sessions, next_arrival, status, episodes;
 };
 
-__device__ __forceinline__ void load_env(const Params& P, int env, int lane, EnvRegs& r) {
-    const int4 s0 = P.scal[2 * env], s1 = P.scal[2 * env + 1];
-    r.t = rfl(s0.x); r.cursor = rfl(s0.y); r.slot = rfl(s0.z); r.moer_day = rfl(s0.w);
-    r.n_sessions = rfl(s1.x); r.next_arrival = rfl(s1.y); r.status = rfl(s1.z); r.episodes = rfl(s1.w);
+// Raw loads of one environment's rows, issued ahead of use (software prefetch: while the wave
+// computes environment e, the rows of its next environment are already in flight).
+struct EnvLoads {
+    int4 s0, s1;      // env scalars (uniform address, broadcast)
+    double rem;       // remaining-demand row element
+    int de;           // packed departure / est_departure
+    float a;          // action element
+    double acc;       // breakdown accumulator (lanes < 3)
+};
+
+__device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& io, int env, int lane) {
+    EnvLoads L;
+    L.s0 = P.scal[2 * env];
+    L.s1 = P.scal[2 * env + 1];
+    const double* rem_row = P.rem + (size_t)env * P.n;        // uniform row bases + 32-bit lane
+    const int* de_row = P.depest + (size_t)env * P.n;
+    const double* acc_row = P.acc + (size_t)env * 3;
+    L.rem = 0.0;
+    L.de = kEmptyDep & 0xffff;
+    L.a = 0.0f;
+    L.acc = 0.0;
     if (lane < P.n) {
-        r.rem = P.rem[(size_t)env * P.n + lane];
-        int de = P.depest[(size_t)env * P.n + lane];
-        r.dep = (int)(short)(de & 0xffff);
-        r.est = de >> 16;
-    } else {
-        r.rem = 0.0; r.dep = kEmptyDep; r.est = 0;
+        L.rem = rem_row[lane];
+        L.de = de_row[lane];
+        L.a = ((const float*)io.actions + (size_t)env * P.n)[lane];
     }
+    if (lane < 3) L.acc = acc_row[lane];
+    return L;
+}
+
+__device__ __forceinline__ void unpack_env(const EnvLoads& L, EnvRegs& r) {
+    r.t = rfl(L.s0.x); r.cursor = rfl(L.s0.y); r.slot = rfl(L.s0.z); r.moer_day = rfl(L.s0.w);
+    r.n_sessions = rfl(L.s1.x); r.next_arrival = rfl(L.s1.y); r.status = rfl(L.s1.z); r.episodes = rfl(L.s1.w);
+    r.rem = L.rem;
+    r.dep = (int)(short)(L.de & 0xffff);
+    r.est = L.de >> 16;
+}
+
+// Normalised action clamped to [0,1] (the reference raises on out-of-range actions, SURVEY §8a
+// a2), as float64.
+__device__ __forceinline__ double unpack_action(const EnvLoads& L, bool& clamped) {
+    float a = L.a;
+    clamped = !(a >= 0.0f && a <= 1.0f);                 // also true for NaN
+    a = fminf(fmaxf(a, 0.0f), 1.0f);                      // NaN -> 0
+    return (double)a;
+}
+
+__device__ __forceinline__ void load_env(const Params& P, int env, int lane, EnvRegs& r) {
+    StepIO none{};
+    none.actions = nullptr;
+    EnvLoads L;
+    L.s0 = P.scal[2 * env];
+    L.s1 = P.scal[2 * env + 1];
+    L.rem = 0.0;
+    L.de = kEmptyDep & 0xffff;
+    if (lane < P.n) {
+        L.rem = (P.rem + (size_t)env * P.n)[lane];
+        L.de = (P.depest + (size_t)env * P.n)[lane];
+    }
+    unpack_env(L, r);
 }
 
 __device__ __forceinline__ void store_env(const Params& P, int env, int lane, const EnvRegs& r) {
+    double* rem_row = P.rem + (size_t)env * P.n;
+    int* de_row = P.depest + (size_t)env * P.n;
     if (lane < P.n) {
-        P.rem[(size_t)env * P.n + lane] = r.rem;
-        P.depest[(size_t)env * P.n + lane] = (r.dep & 0xffff) | (r.est << 16);
+        rem_row[lane] = r.rem;
+        de_row[lane] = (r.dep & 0xffff) | (r.est << 16);
     }
     if (lane == 0) {
         P.scal[2 * env] = make_int4(r.t, r.cursor, r.slot, r.moer_day);
@@ -71,101 +161,107 @@ __device__ __forceinline__ void reset_regs(const Params& P, int slot, EnvRegs& r
         ? rfl((int)P.sessions[(size_t)slot * P.max_sessions].arrival) : kNoArrival;
 }
 
+// MOER part of the observation row for lane j < k+2: [forecast_1..k | prev_moer | t/288]
+__device__ __forceinline__ float moer_obs_value(const Params& P, int lane, int moer_day, int t) {
+    const float* mrow = P.moer_obs + ((size_t)moer_day * EVC_MOER_ROWS + t) * EVC_MOER_COLS;
+    float v = 0.0f;
+    if (lane <= P.k) v = mrow[lane < P.k ? 1 + lane : 0];                      // env.py:390-391
+    if (lane == P.k + 1) v = P.tables->timestep[t];    // (float)(t / 288.0), env.py:392, host table
+    return v;
+}
+
 // env.py:381-394: observation row [demands | est_departures | forecasted_moer | prev_moer | t/288]
-__device__ __forceinline__ void write_obs(const Params& P, float* row, int lane, const EnvRegs& r) {
-    const int n = P.n, k = P.k;
+__device__ __forceinline__ void write_obs(const Params& P, float* row, int lane, const EnvRegs& r,
+                                          float moer_value) {
+    const int n = P.n;
     const bool active = (r.dep != kEmptyDep) && (r.rem > Consts::FULLY_CHARGED_EPS);
-    const size_t mrow = ((size_t)r.moer_day * EVC_MOER_ROWS + r.t) * EVC_MOER_COLS;
     if (lane < n) {
         row[lane] = active ? (float)r.rem : 0.0f;
         row[n + lane] = active ? (float)(r.est - r.t) : 0.0f;
     }
-    if (lane < k) row[2 * n + lane] = P.moer_obs[mrow + 1 + lane];
-    if (lane == 0) {
-        row[2 * n + k] = P.moer_obs[mrow];
-        row[2 * n + k + 1] = (float)((double)r.t / (double)EVC_EPISODE_STEPS);
-    }
-}
-
-// Normalised action of this lane's station, clamped to [0,1] (the reference raises on
-// out-of-range actions), as float64.  DiscreteActionWrapper.action
-// (wrappers.py:43-45) divides in float32.
-__device__ __forceinline__ double load_action(const Params& P, const StepIO& io, int env, int lane,
-                                              bool& clamped) {
-    double a = 0.0;
-    clamped = false;
-    if (lane < P.n) {
-        size_t idx = (size_t)env * P.n + lane;
-        if (io.action_kind == EVC_ACTION_DISCRETE) {
-            long long v = ((const long long*)io.actions)[idx];
-            a = (double)((float)v / (float)(io.bins - 1));
-        } else {
-            a = (double)((const float*)io.actions)[idx];
-        }
-        if (!(a >= 0.0)) { clamped = (a != 0.0); a = 0.0; }
-        else if (a > 1.0) { clamped = true; a = 1.0; }
-    }
-    return a;
+    if (lane < P.k + 2) row[2 * n + lane] = moer_value;
 }
 
 // Upper bound of the projected action (amps): min(32, demand_f32 / A_PERS_TO_KWH)
 // (env.py:188-189 with demands = previous float32 observation, env.py:218).
 __device__ __forceinline__ double demand_cap_amps(const EnvRegs& r) {
     const bool active = (r.dep != kEmptyDep) && (r.rem > Consts::FULLY_CHARGED_EPS);
-    double demand = active ? (double)(float)r.rem : 0.0;
-    double u = demand / Consts::A_PERS_TO_KWH / Consts::ACTION_SCALE_FACTOR;
-    if (u > 1.0) u = 1.0;
-    return u * Consts::ACTION_SCALE_FACTOR;
+    const double demand = (double)(float)r.rem;
+    const double cap = fmin(demand / Consts::A_PERS_TO_KWH, Consts::ACTION_SCALE_FACTOR);
+    return active ? cap : 0.0;
 }
 
-// ||M_c S|| for row c = lane (lane < m) where the class sums S_g are integers given as
-// bit-planes (wave-uniform, computed on the scalar unit).  `scale` rescales the integer sums.
-template <int BITS>
-__device__ __forceinline__ double row_magnitude_planes(const LdsNet& net, const Params& P,
-                                                       int lane_c, const BitPlanes<BITS>& planes) {
+// Two 16-bit class sums per 32-bit word: every lane contributes `q` (< 2^16 / 64) to the field
+// of its own class; WORDS DPP scans give all class sums of the environment.
+template <int WORDS>
+__device__ __forceinline__ void class_sums_u16(const LaneNet& ln, unsigned q, unsigned (&tot)[WORDS]) {
+    const unsigned qs = q << ln.shift;
+#pragma unroll
+    for (int w = 0; w < WORDS; w++) tot[w] = wave_total_u32(ln.word == w ? qs : 0u);
+}
+
+// |M_c S|^2 in float32 for row c = lane (screening only).
+template <int WORDS>
+__device__ __forceinline__ float row_mag2_f32(const LdsNet& net, int c, const unsigned (&tot)[WORDS]) {
+    float re = 0.0f, im = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WORDS; w++) {
+        const float s0 = (float)(tot[w] & 0xffffu), s1 = (float)(tot[w] >> 16);
+        re = fmaf(net.Mre32[2 * w][c], s0, re);
+        im = fmaf(net.Mim32[2 * w][c], s0, im);
+        re = fmaf(net.Mre32[2 * w + 1][c], s1, re);
+        im = fmaf(net.Mim32[2 * w + 1][c], s1, im);
+    }
+    return re * re + im * im;
+}
+
+// |M_c S| in float64 for row c = lane from exact integer class sums (scaled by `scale`).
+template <int WORDS>
+__device__ __forceinline__ double row_mag_f64(const LdsNet& net, int c, const unsigned (&tot)[WORDS],
+                                              double scale) {
     double re = 0.0, im = 0.0;
-    for (int g = 0; g < P.G; g++) {
-        const double s = (double)planes.sum(P.group_mask[g]);
-        re += net.Mre[g][lane_c] * s;
-        im += net.Mim[g][lane_c] * s;
+#pragma unroll
+    for (int w = 0; w < WORDS; w++) {
+        const double s0 = (double)(tot[w] & 0xffffu) * scale, s1 = (double)(tot[w] >> 16) * scale;
+        re += net.Mre[2 * w][c] * s0 + net.Mre[2 * w + 1][c] * s1;
+        im += net.Mim[2 * w][c] * s0 + net.Mim[2 * w + 1][c] * s1;
     }
     return sqrt(re * re + im * im);
 }
 
 // Everything of EVChargingEnv.step after the projection: rounding to legal pilots, one
 // acnsim.Simulator.step pass, observation, reward, bookkeeping, autoreset.
-//   y      : this lane's (projected) action in amps, before rounding
-//   regs   : environment state loaded by load_env
+//   y : this lane's (projected) action in amps, before rounding
+template <int WORDS>
 __device__ __forceinline__ void finish_step(const Params& P, const StepIO& io, const LdsNet& net,
-                                            int env, int lane, double y, double xproj,
-                                            bool clamped, EnvRegs& r) {
+                                            const LaneNet& ln, int env, int lane, double y,
+                                            bool clamped, double acc, bool pilots_screened,
+                                            EnvRegs& r) {
     const int n = P.n, m = P.m;
-    const bool is_cc = (P.cc_mask >> lane) & 1ull;
-    const bool in_net = lane < n;
-
-    // ---- env.py:279 ----
-    const int t1 = r.t + 1;
+    const int t1 = r.t + 1;                                         // env.py:279
+    float moer_value = moer_obs_value(P, lane, r.moer_day, t1);      // issue the loads early
+    const double moer_now = P.moer_hist[(size_t)r.moer_day * EVC_MOER_ROWS + t1];
 
     // ---- env.py:366-378 pilots ----
-    double pilot = in_net ? legal_pilot(y, is_cc) : 0.0;
+    const double pilot = ln.in_net ? legal_pilot(y, ln.is_cc) : 0.0;
 
     // ---- acnsim update_pilots: charge the plugged EVs for iteration t1-1 ----
     const bool occupied = r.dep != kEmptyDep;
-    double amps = 0.0;
-    if (occupied) amps = charge_ev(pilot, r.rem);
-    const double total_rate = wave_sum_f64(amps);                   // env.py:445
+    const double amps = charge_ev(occupied ? pilot : 0.0, r.rem);
+    const double total_rate = wave_sum_f64(amps);                    // env.py:445
 
-    // ---- env.py:449-452 constraint violation of the PILOT schedule ----
-    BitPlanes<6> planes;                                            // pilots are integers <= 32
-    planes.build((int)pilot);
+    // ---- env.py:449-452 constraint violation of the PILOT schedule (exact integer sums) ----
     double excess = 0.0;
-    {
-        double ex = 0.0;
-        if (lane < m) {
-            ex = row_magnitude_planes(net, P, lane, planes) - net.mag[lane];
-            ex = ex > 0.0 ? ex : 0.0;
+    if (!pilots_screened) {                 // (wave-uniform) the y screen did not already clear them
+        unsigned ptot[WORDS];
+        class_sums_u16<WORDS>(ln, (unsigned)(int)pilot, ptot);
+        bool maybe = false;
+        if (lane < m) maybe = !(row_mag2_f32<WORDS>(net, lane, ptot) < net.thr_p2[lane]);
+        if (__ballot(maybe) != 0ull) {                               // rare: evaluate exactly
+            double ex = 0.0;
+            if (lane < m) ex = fmax(row_mag_f64<WORDS>(net, lane, ptot, 1.0) - net.mag[lane], 0.0);
+            excess = wave_sum_f64(ex);
         }
-        if (__ballot(ex > 0.0) != 0ull) excess = wave_sum_f64(ex);
     }
 
     // ---- acnsim event pass at iteration t1: unplug (precedence 0) before plug-in (10) ----
@@ -187,19 +283,14 @@ __device__ __forceinline__ void finish_step(const Params& P, const StepIO& io, c
             ? rfl((int)P.sessions[sidx + 1].arrival) : kNoArrival;
     }
     r.t = t1;
-    if (__ballot(clamped) != 0ull) r.status |= EVC_STATUS_ACTION_CLAMPED;
+    if (__ballot(clamped && ln.in_net) != 0ull) r.status |= EVC_STATUS_ACTION_CLAMPED;
 
     // ---- env.py:431-464 reward ----
-    const double moer_now = P.moer_hist[(size_t)r.moer_day * EVC_MOER_ROWS + t1];
     const double profit = Consts::PROFIT_FACTOR * total_rate;
     const double carbon = Consts::CARBON_COST_FACTOR * total_rate * moer_now;
     const double excess_charge = excess * Consts::VIOLATION_FACTOR;
     const double reward = profit - carbon - excess_charge;
-    double acc = 0.0;
-    if (lane < 3) {
-        acc = P.acc[(size_t)env * 3 + lane];
-        acc += (lane == 0) ? profit : (lane == 1 ? carbon : excess_charge);
-    }
+    acc += (lane == 0) ? profit : (lane == 1 ? carbon : excess_charge);
     const bool done = t1 >= EVC_EPISODE_STEPS;     // event queue empty after the pass at 288
 
     // ---- outputs ----
@@ -207,44 +298,91 @@ __device__ __forceinline__ void finish_step(const Params& P, const StepIO& io, c
         io.out.reward[env] = reward;
         io.out.terminated[env] = done ? 1 : 0;
     }
-    if (io.out.breakdown && lane < 3) io.out.breakdown[(size_t)env * 3 + lane] = acc;
-    if (in_net) {
-        if (io.out.pilots) io.out.pilots[(size_t)env * n + lane] = pilot;
-        if (io.out.rates) io.out.rates[(size_t)env * n + lane] = amps;
-        if (io.out.projected) io.out.projected[(size_t)env * n + lane] = xproj;
+    if (io.out.breakdown && lane < 3) (io.out.breakdown + (size_t)env * 3)[lane] = acc;
+    if (ln.in_net) {
+        if (io.out.pilots) (io.out.pilots + (size_t)env * n)[lane] = pilot;
+        if (io.out.rates) (io.out.rates + (size_t)env * n)[lane] = amps;
+        if (io.out.projected) (io.out.projected + (size_t)env * n)[lane] = y / Consts::ACTION_SCALE_FACTOR;
     }
     float* obs_row = io.out.obs + (size_t)env * P.F;
-    if (done && P.autoreset) {
-        if (io.out.final_obs) write_obs(P, io.out.final_obs + (size_t)env * P.F, lane, r);
-        int next = (r.slot + P.autoreset_stride) % P.bank_slots;
-        int status = r.status, episodes = r.episodes + 1;
-        reset_regs(P, next, r);
-        r.status = status; r.episodes = episodes;
-        acc = 0.0;
-    } else if (done) {
+    if (done) {
         r.episodes += 1;
+        if (P.autoreset) {
+            if (io.out.final_obs) write_obs(P, io.out.final_obs + (size_t)env * P.F, lane, r, moer_value);
+            const int next = (r.slot + P.autoreset_stride) % P.bank_slots;
+            const int status = r.status, episodes = r.episodes;
+            reset_regs(P, next, r);
+            r.status = status; r.episodes = episodes;
+            acc = 0.0;
+            moer_value = moer_obs_value(P, lane, r.moer_day, 0);
+        }
     }
-    write_obs(P, obs_row, lane, r);
-    if (lane < 3) P.acc[(size_t)env * 3 + lane] = acc;
+    write_obs(P, obs_row, lane, r, moer_value);
+    if (lane < 3) (P.acc + (size_t)env * 3)[lane] = acc;
     store_env(P, env, lane, r);
+}
+
+// Closed-form projection for a violated "simple" row (a cap on one station class, e.g. a pod
+// breaker): find nu >= 0 with  sum_{i in class} clip(b_i - nu, 0, h_i) = cap  and return the
+// clipped values.  Safeguarded Newton on the piecewise-linear sum (bracketed; on a flat piece it
+// jumps to the next breakpoint).  Wave-uniform control flow; lanes outside the class pass through.
+__device__ __forceinline__ double waterfill_class(bool in_g, double b, double h, double cap, double y) {
+    double nu = 0.0, lo = 0.0, hi = 64.0;
+    for (int it = 0; it < 80; it++) {
+        const double v = b - nu;
+        const double yv = in_g ? fmin(fmax(v, 0.0), h) : 0.0;
+        const bool is_free = in_g && v > 0.0 && v <= h && h > 0.0;
+        const double f = wave_sum_f64(yv) - cap;
+        if (fabs(f) <= 1e-13 * cap) break;
+        if (f > 0.0) lo = nu; else hi = nu;
+        const int kfree = __popcll(__ballot(is_free));
+        double nxt;
+        if (kfree > 0) {
+            nxt = nu + f / (double)kfree;
+        } else if (f > 0.0) {       // flat piece above the cap: move to the next breakpoint
+            nxt = wave_min_f64((in_g && v > h) ? b - h : 1e300);
+        } else {
+            nxt = 0.5 * (lo + hi);
+        }
+        if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+        nu = nxt;
+    }
+    return in_g ? fmin(fmax(b - nu, 0.0), h) : y;
+}
+
+// exact float64 feasibility of the schedule y: returns the ballot of violated rows and the
+// bitmask of classes whose simple-row cap is exceeded
+template <typename Net>
+__device__ __forceinline__ unsigned long long exact_rows(const Params& P, const Net& net, const LaneNet& ln,
+                                                         int lane, double y, unsigned& cap_viol) {
+    double re = 0.0, im = 0.0;
+    cap_viol = 0u;
+    for (int g = 0; g < P.G; g++) {
+        const double S = wave_sum_f64(ln.gid == g ? y : 0.0);
+        if (lane < P.m) { re += net.Mre[g][lane] * S; im += net.Mim[g][lane] * S; }
+        if (S > P.class_cap[g] * (1.0 + Consts::PROJ_TOL)) cap_viol |= 1u << g;
+    }
+    bool viol = false;
+    if (lane < P.m) viol = sqrt(re * re + im * im) > net.mag[lane] * (1.0 + Consts::PROJ_TOL);
+    return __ballot(viol);
 }
 
 // XCD-aware wave -> environment mapping: workgroup b runs on XCD b % 8 (observed, speed only);
 // each XCD walks one contiguous eighth of the environments so that neighbouring state rows
 // (which share cache lines) meet in the same L2.
 struct EnvWalker {
-    int lo, hi, first, stride;
+    int hi, first, stride;
     __device__ __forceinline__ EnvWalker(int N, int waves_per_block) {
         const int nblk = gridDim.x;
         const int wave = rfl((int)(threadIdx.x >> 6));
         if (nblk % 8 == 0) {
             const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = nblk >> 3;
-            lo = (int)(((long long)N * xcd) >> 3);
+            const int lo = (int)(((long long)N * xcd) >> 3);
             hi = (int)(((long long)N * (xcd + 1)) >> 3);
             first = lo + bx * waves_per_block + wave;
             stride = nbx * waves_per_block;
         } else {
-            lo = 0; hi = N;
+            hi = N;
             first = blockIdx.x * waves_per_block + wave;
             stride = nblk * waves_per_block;
         }
@@ -255,18 +393,35 @@ struct EnvWalker {
 // main step kernel: handles every environment whose projection is the box clip (always the case
 // with project_action_in_env=False); the others are queued for the solver kernel.
 // ------------------------------------------------------------------------------------------
-template <bool PROJECT>
-__global__ __launch_bounds__(256) void step_kernel(Params P, StepIO io) {
+#ifndef EVC_MIN_WAVES
+#define EVC_MIN_WAVES 6
+#endif
+#ifndef EVC_PREFETCH
+#define EVC_PREFETCH 0
+#endif
+template <bool PROJECT, int WORDS>
+__global__ __launch_bounds__(256, EVC_MIN_WAVES) void step_kernel(Params P, StepIO io) {
     __shared__ LdsNet net;
     stage_net(net, P);
     const int lane = threadIdx.x & 63;
-    const int n = P.n, m = P.m, G = P.G;
+    const int m = P.m;
+    const LaneNet ln = lane_net(P, lane);
     EnvWalker walk(P.N, 4);
+    if (walk.first >= walk.hi) return;
+#if EVC_PREFETCH
+    EnvLoads nxt = issue_loads(P, io, walk.first, lane);
+#endif
     for (int env = walk.first; env < walk.hi; env += walk.stride) {
+#if EVC_PREFETCH
+        const EnvLoads cur = nxt;
+        if (env + walk.stride < walk.hi) nxt = issue_loads(P, io, env + walk.stride, lane);
+#else
+        const EnvLoads cur = issue_loads(P, io, env, lane);
+#endif
         EnvRegs r;
-        load_env(P, env, lane, r);
+        unpack_env(cur, r);
         bool clamped;
-        const double a = load_action(P, io, env, lane, clamped);
+        const double a = unpack_action(cur, clamped);
         if (r.t >= EVC_EPISODE_STEPS) {            // step() after termination without autoreset
             if (lane == 0) {
                 P.scal[2 * env + 1].z = r.status | EVC_STATUS_STEP_AFTER_DONE;
@@ -275,39 +430,53 @@ __global__ __launch_bounds__(256) void step_kernel(Params P, StepIO io) {
             }
             continue;
         }
-        double y = a * Consts::ACTION_SCALE_FACTOR;     // env.py:366
+        const double b = a * Consts::ACTION_SCALE_FACTOR;     // env.py:366
+        double y = b;
+        bool pilots_screened = false;
         if (PROJECT) {
             // box part of the projection (exact when no network constraint binds)
             const double h = demand_cap_amps(r);
-            y = fmin(y, h);
-            // 1) conservative integer test: S_g <= sum ceil(8 y)/8, |w_c| <= sum_g |A_cg| S_g
-            BitPlanes<9> planes;
-            planes.build((int)ceil(y * 8.0));
-            bool maybe = false;
+            y = fmin(b, h);
+            // 1) screen: class-sum upper bounds from ceil(8 y) (1/8 A units), float32 rows against
+            //    thresholds that absorb the quantisation slack and the float32 error
+            unsigned ytot[WORDS];
+            class_sums_u16<WORDS>(ln, (unsigned)(int)ceil(y * 8.0), ytot);
+            bool maybe = false, maybe_p = false;
             if (lane < m) {
-                double bound = 0.0;
-                for (int g = 0; g < G; g++)
-                    bound += net.Aabs[g][lane] * (double)planes.sum(P.group_mask[g]);
-                maybe = bound * 0.125 > net.mag[lane];
+                const float mag2 = row_mag2_f32<WORDS>(net, lane, ytot);
+                maybe = !(mag2 < net.thr_y2[lane]);
+                maybe_p = !(mag2 < net.thr_yp2[lane]);
             }
+            pilots_screened = __ballot(maybe_p) == 0ull;   // rounded pilots cannot violate either
             if (__ballot(maybe) != 0ull) {
-                // 2) exact float64 class sums and row magnitudes
-                double re = 0.0, im = 0.0;
-                for (int g = 0; g < G; g++) {
-                    const bool in_g = (P.group_mask[g] >> lane) & 1ull;
-                    const double S = wave_sum_f64(in_g ? y : 0.0);
-                    if (lane < m) { re += net.Mre[g][lane] * S; im += net.Mim[g][lane] * S; }
-                }
-                bool viol = false;
-                if (lane < m)
-                    viol = sqrt(re * re + im * im) > net.mag[lane] * (1.0 + Consts::PROJ_TOL);
-                if (__ballot(viol) != 0ull) {
-                    if (lane == 0) P.slow_list[atomicAdd(P.slow_count, 1)] = env;
-                    continue;                      // the solver kernel steps this environment
+                // 2) exact float64 class sums and row magnitudes (rare)
+                unsigned cap_viol;
+                unsigned long long vrows = exact_rows(P, net, ln, lane, y, cap_viol);
+                if (vrows != 0ull) {
+                    bool solved = false;
+                    if ((vrows & ~(unsigned long long)P.simple_rows) == 0ull) {
+                        // 3) only class caps (pod breakers) are violated: closed-form water-filling;
+                        //    exact if the result satisfies every other row (relaxation argument)
+                        double yw = y;
+                        for (int g = 0; g < P.G; g++)
+                            if ((cap_viol >> g) & 1u)
+                                yw = waterfill_class(ln.gid == g, b, h, P.class_cap[g], yw);
+                        unsigned cv2;
+                        if (exact_rows(P, net, ln, lane, yw, cv2) == 0ull) {
+                            // tie snap of solver-moved values
+                            if (yw != y) yw = fmin(rint(yw * Consts::TIE_SNAP) / Consts::TIE_SNAP, h);
+                            y = yw;
+                            solved = true;
+                        }
+                    }
+                    if (!solved) {
+                        if (lane == 0) P.slow_list[atomicAdd(P.slow_count, 1)] = env;
+                        continue;                  // the solver kernel steps this environment
+                    }
                 }
             }
         }
-        finish_step(P, io, net, env, lane, y, y / Consts::ACTION_SCALE_FACTOR, clamped, r);
+        finish_step<WORDS>(P, io, net, ln, env, lane, y, clamped, cur.acc, pilots_screened, r);
     }
 }
 
@@ -322,15 +491,21 @@ __global__ __launch_bounds__(256) void reset_kernel(Params P, const int* env_ids
     const int env = env_ids ? rfl(env_ids[w]) : w;
     const int slot = slots ? rfl(slots[w]) : (env % P.bank_slots);
     EnvRegs r;
-    r.status = 0; r.episodes = 0;
-    if (env < P.N) {
-        const int4 s1 = P.scal[2 * env + 1];
-        r.status = rfl(s1.z); r.episodes = rfl(s1.w);
-    }
+    const int4 s1 = P.scal[2 * env + 1];
+    r.status = rfl(s1.z); r.episodes = rfl(s1.w);
     reset_regs(P, slot, r);
-    if (lane < 3) P.acc[(size_t)env * 3 + lane] = 0.0;
-    if (obs) write_obs(P, obs + (size_t)env * P.F, lane, r);
+    if (lane < 3) (P.acc + (size_t)env * 3)[lane] = 0.0;
+    if (obs) write_obs(P, obs + (size_t)env * P.F, lane, r, moer_obs_value(P, lane, r.moer_day, 0));
     store_env(P, env, lane, r);
+}
+
+// DiscreteActionWrapper.action (wrappers.py:43-45): int64 {0..bins-1} -> float32 a/(bins-1)
+// (float32 division, as numpy does), written to the engine's float32 action staging buffer.
+__global__ __launch_bounds__(256) void discretize_kernel(const long long* in, float* out, size_t count,
+                                                         int bins) {
+    const float denom = (float)(bins - 1);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i] / denom;
 }
 
 // metrics reduction: sums of the running accumulators + status census.

@@ -164,23 +164,25 @@ __device__ __forceinline__ void solver_cholesky(SolverLds& L, int d, int lane, d
     __syncthreads();
 }
 
+template <int WORDS>
 __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
     __shared__ SolverLds L;
+    const int count = rfl(*P.slow_count);
+    if ((int)blockIdx.x >= count) return;           // nothing queued for this workgroup
     stage_net(L.net, P);
     const int lane = threadIdx.x;
-    const int n = P.n, m = P.m, G = P.G;
-    const int count = rfl(*P.slow_count);
+    const int m = P.m, G = P.G;
+    const LaneNet lnet = lane_net(P, lane);
     SolverLane ln;
-    ln.gid = -1;
-    for (int g = 0; g < G; g++)
-        if (lane < n && ((P.group_mask[g] >> lane) & 1ull)) ln.gid = g;
+    ln.gid = lnet.gid;
 
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
         const int env = rfl(P.slow_list[q]);
+        const EnvLoads cur = issue_loads(P, io, env, lane);
         EnvRegs r;
-        load_env(P, env, lane, r);
+        unpack_env(cur, r);
         bool clamped;
-        const double a = load_action(P, io, env, lane, clamped);
+        const double a = unpack_action(cur, clamped);
         ln.b = a * Consts::ACTION_SCALE_FACTOR;
         ln.h = demand_cap_amps(r);
         if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; }
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
         // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
         double y = ln.y;
         if (y != fmin(ln.b, ln.h)) y = fmin(rint(y * Consts::TIE_SNAP) / Consts::TIE_SNAP, ln.h);
-        finish_step(P, io, L.net, env, lane, y, y / Consts::ACTION_SCALE_FACTOR, clamped, r);
+        finish_step<WORDS>(P, io, L.net, lnet, env, lane, y, clamped, cur.acc, false, r);
         __syncthreads();
     }
 }
