@@ -108,6 +108,51 @@ struct StepIO {
 };
 
 // ------------------------------------------------------------------------------------------
+// row access through raw buffer resources: the SGPR descriptor carries the row's base and its
+// size in bytes, the lane supplies a 32-bit byte offset.  Lanes past the end of the row read 0 and
+// their stores are dropped by the hardware range check, so the row ops need neither 64-bit
+// per-lane address arithmetic nor `lane < n` exec-mask branches.
+// ------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr int kRsrcWord3 = 0x00020000;   // gfx9 raw buffer, DATA_FORMAT = 32
+
+__device__ __forceinline__ rsrc_t row_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, kRsrcWord3);
+}
+__device__ __forceinline__ double buf_ld_f64(rsrc_t r, unsigned off) {
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ unsigned buf_ld_u32(rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ float buf_ld_f32(rsrc_t r, unsigned off) {
+    return __uint_as_float(buf_ld_u32(r, off));
+}
+__device__ __forceinline__ void buf_st_f64(rsrc_t r, unsigned off, double x) {
+    v2u v;
+    v.x = (unsigned)__double2loint(x);
+    v.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void buf_st_u32(rsrc_t r, unsigned off, unsigned x) {
+    __builtin_amdgcn_raw_buffer_store_b32(x, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void buf_st_f32(rsrc_t r, unsigned off, float x) {
+    buf_st_u32(r, off, __float_as_uint(x));
+}
+__device__ __forceinline__ void buf_st_u8(rsrc_t r, unsigned off, unsigned char x) {
+    __builtin_amdgcn_raw_buffer_store_b8(x, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void buf_st_i4(rsrc_t r, unsigned off, int4 x) {
+    v4u v;
+    v.x = (unsigned)x.x; v.y = (unsigned)x.y; v.z = (unsigned)x.z; v.w = (unsigned)x.w;
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
 // wave-level primitives
 // ------------------------------------------------------------------------------------------
 

@@ -87,21 +87,14 @@ struct EnvLoads {
 
 __device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& io, int env, int lane) {
     EnvLoads L;
+    const unsigned n = (unsigned)P.n, ul = (unsigned)lane;
     L.s0 = P.scal[2 * env];
     L.s1 = P.scal[2 * env + 1];
-    const double* rem_row = P.rem + (size_t)env * P.n;        // uniform row bases + 32-bit lane
-    const int* de_row = P.depest + (size_t)env * P.n;
-    const double* acc_row = P.acc + (size_t)env * 3;
-    L.rem = 0.0;
-    L.de = kEmptyDep & 0xffff;
-    L.a = 0.0f;
-    L.acc = 0.0;
-    if (lane < P.n) {
-        L.rem = rem_row[lane];
-        L.de = de_row[lane];
-        L.a = ((const float*)io.actions + (size_t)env * P.n)[lane];
-    }
-    if (lane < 3) L.acc = acc_row[lane];
+    L.rem = buf_ld_f64(row_rsrc(P.rem + (size_t)env * n, n * 8u), ul * 8u);
+    L.de = (int)buf_ld_u32(row_rsrc(P.depest + (size_t)env * n, n * 4u), ul * 4u);
+    L.a = io.actions ? buf_ld_f32(row_rsrc((const float*)io.actions + (size_t)env * n, n * 4u), ul * 4u) : 0.0f;
+    L.acc = buf_ld_f64(row_rsrc(P.acc + (size_t)env * 3, 24u), ul * 8u);
+    if (ul >= n) L.de = kEmptyDep & 0xffff;          // lanes outside the network: empty EVSE
     return L;
 }
 
@@ -125,29 +118,18 @@ __device__ __forceinline__ double unpack_action(const EnvLoads& L, bool& clamped
 __device__ __forceinline__ void load_env(const Params& P, int env, int lane, EnvRegs& r) {
     StepIO none{};
     none.actions = nullptr;
-    EnvLoads L;
-    L.s0 = P.scal[2 * env];
-    L.s1 = P.scal[2 * env + 1];
-    L.rem = 0.0;
-    L.de = kEmptyDep & 0xffff;
-    if (lane < P.n) {
-        L.rem = (P.rem + (size_t)env * P.n)[lane];
-        L.de = (P.depest + (size_t)env * P.n)[lane];
-    }
-    unpack_env(L, r);
+    unpack_env(issue_loads(P, none, env, lane), r);
 }
 
 __device__ __forceinline__ void store_env(const Params& P, int env, int lane, const EnvRegs& r) {
-    double* rem_row = P.rem + (size_t)env * P.n;
-    int* de_row = P.depest + (size_t)env * P.n;
-    if (lane < P.n) {
-        rem_row[lane] = r.rem;
-        de_row[lane] = (r.dep & 0xffff) | (r.est << 16);
-    }
-    if (lane == 0) {
-        P.scal[2 * env] = make_int4(r.t, r.cursor, r.slot, r.moer_day);
-        P.scal[2 * env + 1] = make_int4(r.n_sessions, r.next_arrival, r.status, r.episodes);
-    }
+    const unsigned n = (unsigned)P.n, ul = (unsigned)lane;
+    buf_st_f64(row_rsrc(P.rem + (size_t)env * n, n * 8u), ul * 8u, r.rem);
+    buf_st_u32(row_rsrc(P.depest + (size_t)env * n, n * 4u), ul * 4u,
+               (unsigned)((r.dep & 0xffff) | (r.est << 16)));
+    // the two int4 of scalars: only lane 0 is inside the 16-byte windows
+    const rsrc_t s = row_rsrc(P.scal + 2 * (size_t)env, 32u);
+    buf_st_i4(s, ul * 32u, make_int4(r.t, r.cursor, r.slot, r.moer_day));
+    buf_st_i4(s, ul * 32u + 16u, make_int4(r.n_sessions, r.next_arrival, r.status, r.episodes));
 }
 
 // Puts environment registers into the state right after EVChargingEnv.reset (env.py:319-333)
@@ -164,22 +146,20 @@ __device__ __forceinline__ void reset_regs(const Params& P, int slot, EnvRegs& r
 // MOER part of the observation row for lane j < k+2: [forecast_1..k | prev_moer | t/288]
 __device__ __forceinline__ float moer_obs_value(const Params& P, int lane, int moer_day, int t) {
     const float* mrow = P.moer_obs + ((size_t)moer_day * EVC_MOER_ROWS + t) * EVC_MOER_COLS;
-    float v = 0.0f;
-    if (lane <= P.k) v = mrow[lane < P.k ? 1 + lane : 0];                      // env.py:390-391
-    if (lane == P.k + 1) v = P.tables->timestep[t];    // (float)(t / 288.0), env.py:392, host table
-    return v;
+    const unsigned idx = (lane < P.k) ? (unsigned)lane + 1u : 0u;             // env.py:390-391
+    float v = buf_ld_f32(row_rsrc(mrow, EVC_MOER_COLS * 4u), idx * 4u);
+    const float ts = P.tables->timestep[t];             // (float)(t / 288.0), env.py:392, host table
+    return (lane == P.k + 1) ? ts : v;
 }
 
 // env.py:381-394: observation row [demands | est_departures | forecasted_moer | prev_moer | t/288]
 __device__ __forceinline__ void write_obs(const Params& P, float* row, int lane, const EnvRegs& r,
                                           float moer_value) {
-    const int n = P.n;
+    const unsigned n = (unsigned)P.n, ul = (unsigned)lane;
     const bool active = (r.dep != kEmptyDep) && (r.rem > Consts::FULLY_CHARGED_EPS);
-    if (lane < n) {
-        row[lane] = active ? (float)r.rem : 0.0f;
-        row[n + lane] = active ? (float)(r.est - r.t) : 0.0f;
-    }
-    if (lane < P.k + 2) row[2 * n + lane] = moer_value;
+    buf_st_f32(row_rsrc(row, n * 4u), ul * 4u, active ? (float)r.rem : 0.0f);
+    buf_st_f32(row_rsrc(row + n, n * 4u), ul * 4u, active ? (float)(r.est - r.t) : 0.0f);
+    buf_st_f32(row_rsrc(row + 2 * n, (unsigned)(P.k + 2) * 4u), ul * 4u, moer_value);
 }
 
 // Upper bound of the projected action (amps): min(32, demand_f32 / A_PERS_TO_KWH)
@@ -232,12 +212,17 @@ __device__ __forceinline__ double row_mag_f64(const LdsNet& net, int c, const un
 // Everything of EVChargingEnv.step after the projection: rounding to legal pilots, one
 // acnsim.Simulator.step pass, observation, reward, bookkeeping, autoreset.
 //   y : this lane's (projected) action in amps, before rounding
+// Ordering is for instruction-level overlap inside the in-order wave: the reductions (DPP
+// ladders) are issued first, everything that does not depend on them (event pass, observation
+// and state stores) follows, and the only data-dependent branch (exact constraint excess, rare)
+// is taken last.
 template <int WORDS>
 __device__ __forceinline__ void finish_step(const Params& P, const StepIO& io, const LdsNet& net,
                                             const LaneNet& ln, int env, int lane, double y,
                                             bool clamped, double acc, bool pilots_screened,
                                             EnvRegs& r) {
-    const int n = P.n, m = P.m;
+    const unsigned n = (unsigned)P.n;
+    const int m = P.m;
     const int t1 = r.t + 1;                                         // env.py:279
     float moer_value = moer_obs_value(P, lane, r.moer_day, t1);      // issue the loads early
     const double moer_now = P.moer_hist[(size_t)r.moer_day * EVC_MOER_ROWS + t1];
@@ -250,19 +235,22 @@ __device__ __forceinline__ void finish_step(const Params& P, const StepIO& io, c
     const double amps = charge_ev(occupied ? pilot : 0.0, r.rem);
     const double total_rate = wave_sum_f64(amps);                    // env.py:445
 
-    // ---- env.py:449-452 constraint violation of the PILOT schedule (exact integer sums) ----
-    double excess = 0.0;
+    // ---- env.py:449-452 screen of the PILOT schedule (exact integer class sums, float32 rows) ----
+    unsigned ptot[WORDS];
+    unsigned long long maybe_rows = 0ull;
     if (!pilots_screened) {                 // (wave-uniform) the y screen did not already clear them
-        unsigned ptot[WORDS];
         class_sums_u16<WORDS>(ln, (unsigned)(int)pilot, ptot);
         bool maybe = false;
         if (lane < m) maybe = !(row_mag2_f32<WORDS>(net, lane, ptot) < net.thr_p2[lane]);
-        if (__ballot(maybe) != 0ull) {                               // rare: evaluate exactly
-            double ex = 0.0;
-            if (lane < m) ex = fmax(row_mag_f64<WORDS>(net, lane, ptot, 1.0) - net.mag[lane], 0.0);
-            excess = wave_sum_f64(ex);
-        }
+        maybe_rows = __ballot(maybe);
     }
+
+    // ---- optional per-station debug outputs ----
+    if (io.out.pilots) buf_st_f64(row_rsrc(io.out.pilots + (size_t)env * n, n * 8u), lane * 8u, pilot);
+    if (io.out.rates) buf_st_f64(row_rsrc(io.out.rates + (size_t)env * n, n * 8u), lane * 8u, amps);
+    if (io.out.projected)
+        buf_st_f64(row_rsrc(io.out.projected + (size_t)env * n, n * 8u), lane * 8u,
+                   y / Consts::ACTION_SCALE_FACTOR);
 
     // ---- acnsim event pass at iteration t1: unplug (precedence 0) before plug-in (10) ----
     if (occupied && r.dep <= t1) { r.dep = kEmptyDep; r.est = 0; r.rem = 0.0; }
@@ -284,42 +272,42 @@ __device__ __forceinline__ void finish_step(const Params& P, const StepIO& io, c
     }
     r.t = t1;
     if (__ballot(clamped && ln.in_net) != 0ull) r.status |= EVC_STATUS_ACTION_CLAMPED;
+    const bool done = t1 >= EVC_EPISODE_STEPS;     // event queue empty after the pass at 288
 
-    // ---- env.py:431-464 reward ----
+    // ---- observation + state write-back (independent of the reductions) ----
+    float* obs_row = io.out.obs + (size_t)env * P.F;
+    EnvRegs w = r;                                  // state to store (reset state on autoreset)
+    if (done) {
+        r.episodes += 1;
+        w.episodes = r.episodes;
+        if (P.autoreset) {
+            if (io.out.final_obs) write_obs(P, io.out.final_obs + (size_t)env * P.F, lane, r, moer_value);
+            const int next = (r.slot + P.autoreset_stride) % P.bank_slots;
+            reset_regs(P, next, w);
+            w.status = r.status; w.episodes = r.episodes;
+            moer_value = moer_obs_value(P, lane, w.moer_day, 0);
+        }
+    }
+    write_obs(P, obs_row, lane, w, moer_value);
+    store_env(P, env, lane, w);
+
+    // ---- env.py:431-464 reward (needs the reductions) ----
+    double excess = 0.0;
+    if (maybe_rows != 0ull) {                                        // rare: evaluate exactly
+        double ex = 0.0;
+        if (lane < m) ex = fmax(row_mag_f64<WORDS>(net, lane, ptot, 1.0) - net.mag[lane], 0.0);
+        excess = wave_sum_f64(ex);
+    }
     const double profit = Consts::PROFIT_FACTOR * total_rate;
     const double carbon = Consts::CARBON_COST_FACTOR * total_rate * moer_now;
     const double excess_charge = excess * Consts::VIOLATION_FACTOR;
     const double reward = profit - carbon - excess_charge;
     acc += (lane == 0) ? profit : (lane == 1 ? carbon : excess_charge);
-    const bool done = t1 >= EVC_EPISODE_STEPS;     // event queue empty after the pass at 288
-
-    // ---- outputs ----
-    if (lane == 0) {
-        io.out.reward[env] = reward;
-        io.out.terminated[env] = done ? 1 : 0;
-    }
-    if (io.out.breakdown && lane < 3) (io.out.breakdown + (size_t)env * 3)[lane] = acc;
-    if (ln.in_net) {
-        if (io.out.pilots) (io.out.pilots + (size_t)env * n)[lane] = pilot;
-        if (io.out.rates) (io.out.rates + (size_t)env * n)[lane] = amps;
-        if (io.out.projected) (io.out.projected + (size_t)env * n)[lane] = y / Consts::ACTION_SCALE_FACTOR;
-    }
-    float* obs_row = io.out.obs + (size_t)env * P.F;
-    if (done) {
-        r.episodes += 1;
-        if (P.autoreset) {
-            if (io.out.final_obs) write_obs(P, io.out.final_obs + (size_t)env * P.F, lane, r, moer_value);
-            const int next = (r.slot + P.autoreset_stride) % P.bank_slots;
-            const int status = r.status, episodes = r.episodes;
-            reset_regs(P, next, r);
-            r.status = status; r.episodes = episodes;
-            acc = 0.0;
-            moer_value = moer_obs_value(P, lane, r.moer_day, 0);
-        }
-    }
-    write_obs(P, obs_row, lane, r, moer_value);
-    if (lane < 3) (P.acc + (size_t)env * 3)[lane] = acc;
-    store_env(P, env, lane, r);
+    buf_st_f64(row_rsrc(io.out.reward + env, 8u), lane * 8u, reward);              // lane 0 only
+    buf_st_u8(row_rsrc(io.out.terminated + env, 1u), lane, done ? 1 : 0);            // lane 0 only
+    if (io.out.breakdown) buf_st_f64(row_rsrc(io.out.breakdown + (size_t)env * 3, 24u), lane * 8u, acc);
+    buf_st_f64(row_rsrc(P.acc + (size_t)env * 3, 24u), lane * 8u, (done && P.autoreset) ? 0.0 : acc);
+    r = w;
 }
 
 // Closed-form projection for a violated "simple" row (a cap on one station class, e.g. a pod
@@ -394,7 +382,7 @@ struct EnvWalker {
 // with project_action_in_env=False); the others are queued for the solver kernel.
 // ------------------------------------------------------------------------------------------
 #ifndef EVC_MIN_WAVES
-#define EVC_MIN_WAVES 6
+#define EVC_MIN_WAVES 1
 #endif
 #ifndef EVC_PREFETCH
 #define EVC_PREFETCH 0
@@ -422,6 +410,19 @@ __global__ __launch_bounds__(256, EVC_MIN_WAVES) void step_kernel(Params P, Step
         unpack_env(cur, r);
         bool clamped;
         const double a = unpack_action(cur, clamped);
+#ifdef EVC_ABL_COPY
+        {
+            r.t += 1; r.rem += a;
+            float mv = moer_obs_value(P, lane, r.moer_day, r.t);
+            buf_st_f64(row_rsrc(io.out.reward + env, 8u), lane * 8u, a);
+            buf_st_u8(row_rsrc(io.out.terminated + env, 1u), lane, 0);
+            if (io.out.breakdown) buf_st_f64(row_rsrc(io.out.breakdown + (size_t)env * 3, 24u), lane * 8u, cur.acc);
+            write_obs(P, io.out.obs + (size_t)env * P.F, lane, r, mv);
+            buf_st_f64(row_rsrc(P.acc + (size_t)env * 3, 24u), lane * 8u, cur.acc + a);
+            store_env(P, env, lane, r);
+            continue;
+        }
+#endif
         if (r.t >= EVC_EPISODE_STEPS) {            // step() after termination without autoreset
             if (lane == 0) {
                 P.scal[2 * env + 1].z = r.status | EVC_STATUS_STEP_AFTER_DONE;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256) void reset_kernel(Params P, const int* env_ids
     const int4 s1 = P.scal[2 * env + 1];
     r.status = rfl(s1.z); r.episodes = rfl(s1.w);
     reset_regs(P, slot, r);
-    if (lane < 3) (P.acc + (size_t)env * 3)[lane] = 0.0;
+    buf_st_f64(row_rsrc(P.acc + (size_t)env * 3, 24u), lane * 8u, 0.0);
     if (obs) write_obs(P, obs + (size_t)env * P.F, lane, r, moer_obs_value(P, lane, r.moer_day, 0));
     store_env(P, env, lane, r);
 }
