@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "evc_solver.h"
+#include "evc_quad.h"
 
 using namespace evc;
 
@@ -80,7 +81,8 @@ struct evc_engine {
     bool ev_valid = false, ev_slow = false;
     // host mirrors
     unsigned long long env_steps = 0;
-    int step_grid = 0, solver_grid = 0;
+    int step_grid = 0, solver_grid = 0, quad_grid = 0;
+    bool use_quad = false;
 };
 
 namespace {
@@ -197,6 +199,16 @@ void compute_grids(evc_engine* e) {
     if (blocks >= 8) blocks -= blocks % 8;
     e->step_grid = blocks;
     e->solver_grid = e->P.N < 1024 ? e->P.N : 1024;
+    int qblocks = (((e->P.N + 3) / 4) + 3) / 4;          // quads per wave, 4 waves per workgroup
+    if (qblocks > cap) qblocks = cap;
+    if (qblocks >= 8) qblocks -= qblocks % 8;
+    if (qblocks < 1) qblocks = 1;
+    e->quad_grid = qblocks;
+    // the 4-environments-per-wavefront kernel evaluates constraint row c in lane c of a 16-lane
+    // row and addresses whole arrays with 32-bit byte offsets
+    const char* kk = getenv("EVC_KERNEL");
+    const bool fits32 = (double)e->P.N * e->P.F * 4.0 < 2.0e9 && (double)e->P.N * e->P.n * 8.0 < 2.0e9;
+    e->use_quad = e->P.m <= 16 && fits32 && !(kk && strcmp(kk, "wave") == 0);
 }
 
 int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bins,
@@ -224,6 +236,29 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
     if (e->P.project) HIP_TRY(hipMemsetAsync(e->d_slow_count, 0, sizeof(int), e->stream));
     const int words = (e->P.G + 1) / 2;
+    const bool dbg = out->pilots || out->rates || out->projected;
+#define EVC_LAUNCH_QUAD(W)                                                                         \
+    case W:                                                                                        \
+        if (e->P.project) {                                                                        \
+            if (dbg) hipLaunchKernelGGL((step_kernel_quad<true, W, true>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
+            else hipLaunchKernelGGL((step_kernel_quad<true, W, false>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
+            if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
+            hipLaunchKernelGGL((solver_step_kernel<W>), dim3(e->solver_grid), dim3(64), 0,         \
+                               e->stream, e->P, io);                                               \
+        } else {                                                                                   \
+            if (dbg) hipLaunchKernelGGL((step_kernel_quad<false, W, true>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
+            else hipLaunchKernelGGL((step_kernel_quad<false, W, false>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
+            if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
+        }                                                                                          \
+        break;
+    if (e->use_quad) {
+        switch (words) {
+            EVC_LAUNCH_QUAD(1) EVC_LAUNCH_QUAD(2) EVC_LAUNCH_QUAD(3) EVC_LAUNCH_QUAD(4)
+            EVC_LAUNCH_QUAD(5) EVC_LAUNCH_QUAD(6) EVC_LAUNCH_QUAD(7) EVC_LAUNCH_QUAD(8)
+            default: return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
+        }
+    } else
+#undef EVC_LAUNCH_QUAD
 #define EVC_LAUNCH(W)                                                                              \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \

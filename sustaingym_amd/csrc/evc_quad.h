@@ -1,0 +1,344 @@
+// evc_quad.h — the streaming step kernel: FOUR environments per wavefront.
+//
+// Layout: wavefront = 4 DPP rows of 16 lanes; row r simulates environment 4*quad + r, lane q of a
+// row owns stations q, q+16, q+32, q+48 ("slots" j = 0..3, n <= 64).  What is uniform per
+// environment (t, cursor, bank slot, MOER day, status, reward terms) is replicated across the 16
+// lanes of its row in VGPRs; cross-station reductions are 4-step DPP `row_ror` all-reduces that
+// never leave the row.  Compared with one environment per wavefront this amortises all per-
+// environment work (reductions, constraint rows, scalar bookkeeping, address generation) over four
+// environments and removes almost all scalar-unit work; per-station work is unchanged.  Rows whose
+// projection screen is inconclusive are appended to the slow queue and finished by the
+// wave-per-environment kernel (evc_solver.h); they write nothing here.
+//
+// Requires m <= 16 (constraint row c is evaluated by lane c of every row).
+#pragma once
+
+#include "evc_kernels.h"
+
+namespace evc {
+
+constexpr int kSlots = 4;
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_ror_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned row_allreduce_u32(unsigned v) {
+    v += dpp_ror_u32<0x121>(v);   // row_ror:1
+    v += dpp_ror_u32<0x122>(v);   // row_ror:2
+    v += dpp_ror_u32<0x124>(v);   // row_ror:4
+    v += dpp_ror_u32<0x128>(v);   // row_ror:8
+    return v;
+}
+__device__ __forceinline__ double row_allreduce_f64(double v) {
+    v += dpp_f64<0x121, 0xf, false>(v);
+    v += dpp_f64<0x122, 0xf, false>(v);
+    v += dpp_f64<0x124, 0xf, false>(v);
+    v += dpp_f64<0x128, 0xf, false>(v);
+    return v;
+}
+// does any lane of MY row have `flag` set?
+__device__ __forceinline__ bool row_any(bool flag, unsigned row) {
+    const unsigned long long b = __ballot(flag);
+    return ((unsigned)(b >> (row * 16u)) & 0xffffu) != 0u;
+}
+
+constexpr unsigned kOob = 0xffffffffu;     // byte offset that is out of range for every buffer
+constexpr unsigned kBadIdx = 0x1fffffffu;  // element index whose *4 and *8 byte offsets are out of range
+                                           // (arrays are < 2 GiB, checked at evc_create)
+
+// |M_c S|^2 (float32 screen) / |M_c S| (float64) for row c = q from per-row packed class sums
+template <int WORDS>
+__device__ __forceinline__ float quad_mag2_f32(const LdsNet& net, unsigned c, const unsigned (&tot)[WORDS]) {
+    float re = 0.0f, im = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WORDS; w++) {
+        const float s0 = (float)(tot[w] & 0xffffu), s1 = (float)(tot[w] >> 16);
+        re = fmaf(net.Mre32[2 * w][c], s0, re);
+        im = fmaf(net.Mim32[2 * w][c], s0, im);
+        re = fmaf(net.Mre32[2 * w + 1][c], s1, re);
+        im = fmaf(net.Mim32[2 * w + 1][c], s1, im);
+    }
+    return re * re + im * im;
+}
+
+template <bool PROJECT, int WORDS, bool DBG>
+__global__ __launch_bounds__(256) void step_kernel_quad(Params P, StepIO io) {
+    __shared__ LdsNet net;
+    stage_net(net, P);
+    const unsigned lane = threadIdx.x & 63u, q = lane & 15u, row = lane >> 4;
+    const unsigned n = (unsigned)P.n, F = (unsigned)P.F;
+    const unsigned m = (unsigned)P.m, k = (unsigned)P.k;
+    const unsigned N = (unsigned)P.N;
+
+    // ---- per-lane, per-slot station constants ----
+    bool st_valid[kSlots], st_cc[kSlots];
+    int st_word[kSlots], st_shift[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        const unsigned s = (unsigned)j * 16u + q;
+        st_valid[j] = s < n;
+        st_cc[j] = (P.cc_mask >> s) & 1ull;
+        int gid = 0;
+        for (int g = 0; g < P.G; g++)
+            if ((P.group_mask[g] >> s) & 1ull) gid = g;
+        st_word[j] = gid >> 1;
+        st_shift[j] = (gid & 1) << 4;
+    }
+
+    // ---- buffer resources over whole arrays (lane supplies a 32-bit byte offset) ----
+    const rsrc_t r_rem = row_rsrc(P.rem, N * n * 8u);
+    const rsrc_t r_de = row_rsrc(P.depest, N * n * 4u);
+    const rsrc_t r_act = row_rsrc(io.actions, N * n * 4u);
+    const rsrc_t r_scal = row_rsrc(P.scal, N * 32u);
+    const rsrc_t r_acc = row_rsrc(P.acc, N * 24u);
+    const rsrc_t r_obs = row_rsrc(io.out.obs, N * F * 4u);
+    const rsrc_t r_moer = row_rsrc(P.moer_obs, (unsigned)P.moer_days * EVC_MOER_ROWS * EVC_MOER_COLS * 4u);
+    const rsrc_t r_hist = row_rsrc(P.moer_hist, (unsigned)P.moer_days * EVC_MOER_ROWS * 8u);
+    const rsrc_t r_ts = row_rsrc(P.tables->timestep, EVC_MOER_ROWS * 4u);
+    const rsrc_t r_rew = row_rsrc(io.out.reward, N * 8u);
+    const rsrc_t r_term = row_rsrc(io.out.terminated, N);
+    const rsrc_t r_bd = row_rsrc(io.out.breakdown, io.out.breakdown ? N * 24u : 0u);
+    const rsrc_t r_sess = row_rsrc(P.sessions, (unsigned)P.bank_slots * (unsigned)P.max_sessions * 8u);
+    const rsrc_t r_req = row_rsrc(P.requested, (unsigned)P.bank_slots * (unsigned)P.max_sessions * 8u);
+
+    const unsigned nquads = (N + 3u) >> 2;
+    EnvWalker walk((int)nquads, 4);            // XCD-aware walk over quads
+    for (int quad = walk.first; quad < walk.hi; quad += walk.stride) {
+        const unsigned env = (unsigned)quad * 4u + row;
+        const bool ev = env < N;
+
+        // ---- loads: scalars (row-uniform, replicated), station rows, action row ----
+        const unsigned soff = ev ? env * 32u : kOob;
+        const v4u s0 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 0, 0);
+        const v4u s1 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 16, 0);
+        double rem[kSlots];
+        int dep[kSlots], est[kSlots];
+        float act[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const bool v = ev && st_valid[j];
+            const unsigned idx = v ? env * n + (unsigned)j * 16u + q : kBadIdx;
+            rem[j] = buf_ld_f64(r_rem, idx * 8u);
+            const unsigned de = buf_ld_u32(r_de, idx * 4u);
+            act[j] = buf_ld_f32(r_act, idx * 4u);
+            dep[j] = v ? (int)(short)(de & 0xffffu) : kEmptyDep;
+            est[j] = (int)de >> 16;
+        }
+        const double acc_in = buf_ld_f64(r_acc, (ev && q < 3u) ? env * 24u + q * 8u : kOob);
+
+        int t = (int)s0.x, cursor = (int)s0.y, slot = (int)s0.z, moer_day = (int)s0.w;
+        int n_sessions = (int)s1.x, next_arrival = (int)s1.y, status = (int)s1.z, episodes = (int)s1.w;
+        const bool after_done = ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
+        bool live = ev && !after_done;
+        const int t1 = t + 1;
+
+        // MOER loads for t1 (row-uniform addresses)
+        const unsigned mrow = live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) : 0u;
+        const double moer_now = buf_ld_f64(r_hist, live ? mrow * 8u : kOob);
+        float mo[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const unsigned idx = (unsigned)p * 16u + q;                 // position in [forecast | prev | ts]
+            const unsigned col = idx < k ? idx + 1u : 0u;
+            mo[p] = buf_ld_f32(r_moer, (live && idx <= k) ? (mrow * EVC_MOER_COLS + col) * 4u : kOob);
+            if (idx == k + 1u) mo[p] = buf_ld_f32(r_ts, live ? (unsigned)t1 * 4u : kOob);
+        }
+
+        // ---- action -> y (box clip), pilots, battery; accumulate reductions ----
+        bool clamped = false;
+        double y[kSlots];
+        unsigned ywords[WORDS], pwords[WORDS];
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) { ywords[w] = 0u; pwords[w] = 0u; }
+        double amps_sum = 0.0;
+        double pilot[kSlots], amps[kSlots];      // kept only for the DBG outputs
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            float a = act[j];
+            clamped = clamped || (st_valid[j] && !(a >= 0.0f && a <= 1.0f));
+            a = fminf(fmaxf(a, 0.0f), 1.0f);
+            double yy = (double)a * Consts::ACTION_SCALE_FACTOR;        // env.py:366
+            if (PROJECT) {
+                const bool active = (dep[j] != kEmptyDep) && (rem[j] > Consts::FULLY_CHARGED_EPS);
+                // demand / A_PERS_TO_KWH (env.py:188-189,218) as reciprocal multiply + one fma
+                // correction (Markstein): correctly rounded like the divide, 3 instructions
+                const double dm = (double)(float)rem[j];
+                const double q0 = dm * (1.0 / Consts::A_PERS_TO_KWH);
+                const double rr = fma(-q0, Consts::A_PERS_TO_KWH, dm);
+                const double cap = fmin(fma(rr, 1.0 / Consts::A_PERS_TO_KWH, q0), Consts::ACTION_SCALE_FACTOR);
+                yy = fmin(yy, active ? cap : 0.0);
+                const unsigned qy = (unsigned)(int)ceil(yy * 8.0) << st_shift[j];
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) ywords[w] += (st_word[j] == w) ? qy : 0u;
+            }
+            y[j] = yy;
+            const double pl = st_valid[j] ? legal_pilot(yy, st_cc[j]) : 0.0;
+            pilot[j] = pl;
+            const unsigned qp = (unsigned)(int)pl << st_shift[j];
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) pwords[w] += (st_word[j] == w) ? qp : 0u;
+            const bool occupied = dep[j] != kEmptyDep;
+            amps[j] = charge_ev(occupied ? pl : 0.0, rem[j]);
+            amps_sum += amps[j];
+        }
+
+        // ---- projection screen (PROJECT): inconclusive rows go to the slow kernel ----
+        bool pilots_screened = false;
+        if (PROJECT) {
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) ywords[w] = row_allreduce_u32(ywords[w]);
+            bool maybe = false, maybe_p = false;
+            if (q < m) {
+                const float mag2 = quad_mag2_f32<WORDS>(net, q, ywords);
+                maybe = !(mag2 < net.thr_y2[q]);
+                maybe_p = !(mag2 < net.thr_yp2[q]);
+            }
+            const bool queue_me = live && row_any(maybe, row);
+            pilots_screened = !row_any(maybe_p, row);
+            if (queue_me && q == 0u) P.slow_list[atomicAdd(P.slow_count, 1)] = (int)env;
+            live = live && !queue_me;                 // queued rows write nothing here
+        }
+
+        // ---- reductions inside the row ----
+        const double total_rate = row_allreduce_f64(amps_sum);           // env.py:445
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) pwords[w] = row_allreduce_u32(pwords[w]);
+        double excess = 0.0;
+        {
+            bool maybe = false;
+            if (q < m && !pilots_screened) maybe = !(quad_mag2_f32<WORDS>(net, q, pwords) < net.thr_p2[q]);
+            if (__ballot(maybe && live) != 0ull) {                       // rare: exact evaluation
+                double ex = 0.0;
+                if (q < m) ex = fmax(row_mag_f64<WORDS>(net, (int)q, pwords, 1.0) - net.mag[q], 0.0);
+                excess = row_allreduce_f64(ex);
+            }
+        }
+
+        // ---- acnsim event pass at iteration t1: unplug (precedence 0) before plug-in (10) ----
+#pragma unroll
+        for (int j = 0; j < kSlots; j++)
+            if (dep[j] != kEmptyDep && dep[j] <= t1) { dep[j] = kEmptyDep; est[j] = 0; rem[j] = 0.0; }
+        bool pending = live && next_arrival <= t1 && cursor < n_sessions;
+        while (__ballot(pending) != 0ull) {
+            const unsigned sidx = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
+            const v2u sv = __builtin_amdgcn_raw_buffer_load_b64(r_sess, pending ? (int)(sidx * 8u) : (int)kOob, 0, 0);
+            const double rq = buf_ld_f64(r_req, pending ? sidx * 8u : kOob);
+            const int s_dep = (int)(short)(sv.x >> 16);
+            const int s_est = (int)(short)(sv.y & 0xffffu);
+            const unsigned s_st = sv.y >> 16;
+            const bool mine = pending && (s_st & 15u) == q;
+            const unsigned sj = s_st >> 4;
+            bool busy = false;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) busy = busy || (mine && sj == (unsigned)j && dep[j] != kEmptyDep);
+            const bool row_busy = row_any(busy, row);
+            if (pending && row_busy) status |= EVC_STATUS_OCCUPIED;      // acnportal: StationOccupiedError
+#pragma unroll
+            for (int j = 0; j < kSlots; j++)
+                if (mine && !row_busy && sj == (unsigned)j) { dep[j] = s_dep; est[j] = s_est; rem[j] = rq; }
+            if (pending) {
+                cursor += 1;
+                next_arrival = kNoArrival;
+            }
+            const bool more = pending && cursor < n_sessions;
+            const unsigned nx = buf_ld_u32(r_sess, more ? (sidx + 1u) * 8u : kOob);
+            if (more) next_arrival = (int)(short)(nx & 0xffffu);
+            pending = more && next_arrival <= t1;
+        }
+        if (live) t = t1;
+        if (live && row_any(clamped, row)) status |= EVC_STATUS_ACTION_CLAMPED;
+        const bool done = live && t1 >= EVC_EPISODE_STEPS;
+        if (after_done) status |= EVC_STATUS_STEP_AFTER_DONE;
+
+        // ---- reward (env.py:431-464) ----
+        const double profit = Consts::PROFIT_FACTOR * total_rate;
+        const double carbon = Consts::CARBON_COST_FACTOR * total_rate * moer_now;
+        const double excess_charge = excess * Consts::VIOLATION_FACTOR;
+        const double reward = after_done ? 0.0 : profit - carbon - excess_charge;
+        const double acc = acc_in + ((q == 0u) ? profit : (q == 1u ? carbon : excess_charge));
+        const bool wr = live || after_done;           // rows that report reward / terminated
+        buf_st_f64(r_rew, (wr && q == 0u) ? env * 8u : kOob, reward);
+        buf_st_u8(r_term, (wr && q == 0u) ? env : kOob, (done || after_done) ? 1 : 0);
+        buf_st_f64(r_bd, (live && q < 3u) ? env * 24u + q * 8u : kOob, acc);
+        if (DBG) {                                                        // debug / parity outputs
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) {
+                const size_t idx = (size_t)env * n + (unsigned)j * 16u + q;
+                if (live && st_valid[j]) {
+                    if (io.out.pilots) io.out.pilots[idx] = pilot[j];
+                    if (io.out.rates) io.out.rates[idx] = amps[j];
+                    if (io.out.projected) io.out.projected[idx] = y[j] / Consts::ACTION_SCALE_FACTOR;
+                }
+            }
+        }
+
+        // ---- autoreset (gymnasium VectorEnv): terminal observation, then next episode's state ----
+        const bool do_reset = done && P.autoreset;
+        if (done) episodes += 1;
+        if (__ballot(do_reset) != 0ull) {
+            if (io.out.final_obs) {
+                const rsrc_t r_fin = row_rsrc(io.out.final_obs, N * F * 4u);
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) {
+                    const bool active = (dep[j] != kEmptyDep) && (rem[j] > Consts::FULLY_CHARGED_EPS);
+                    const unsigned o = (do_reset && st_valid[j]) ? (env * F + (unsigned)j * 16u + q) * 4u : kOob;
+                    buf_st_f32(r_fin, o, active ? (float)rem[j] : 0.0f);
+                    buf_st_f32(r_fin, o == kOob ? kOob : o + n * 4u, active ? (float)(est[j] - t) : 0.0f);
+                }
+#pragma unroll
+                for (int p = 0; p < 3; p++) {
+                    const unsigned idx = (unsigned)p * 16u + q;
+                    buf_st_f32(r_fin, (do_reset && idx < k + 2u) ? (env * F + 2u * n + idx) * 4u : kOob, mo[p]);
+                }
+            }
+            if (do_reset) {
+                const int next = (slot + P.autoreset_stride) % P.bank_slots;
+                slot = next;
+                t = 0; cursor = 0;
+                moer_day = P.slot_moer_day[next];
+                n_sessions = P.n_sessions[next];
+                next_arrival = n_sessions > 0 ? (int)P.sessions[(size_t)next * P.max_sessions].arrival : kNoArrival;
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) { rem[j] = 0.0; dep[j] = kEmptyDep; est[j] = 0; }
+            }
+            const unsigned mrow0 = (unsigned)moer_day * EVC_MOER_ROWS;
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const unsigned idx = (unsigned)p * 16u + q;
+                const unsigned col = idx < k ? idx + 1u : 0u;
+                const float v = buf_ld_f32(r_moer, (do_reset && idx <= k) ? (mrow0 * EVC_MOER_COLS + col) * 4u : kOob);
+                if (do_reset) mo[p] = (idx == k + 1u) ? 0.0f : v;
+            }
+        }
+
+        // ---- observation (env.py:381-394) + state write-back ----
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const bool active = (dep[j] != kEmptyDep) && (rem[j] > Consts::FULLY_CHARGED_EPS);
+            const bool wv = live && st_valid[j];
+            const unsigned sidx = wv ? env * n + (unsigned)j * 16u + q : kBadIdx;
+            const unsigned oidx = wv ? env * F + (unsigned)j * 16u + q : kBadIdx;
+            buf_st_f32(r_obs, oidx * 4u, active ? (float)rem[j] : 0.0f);
+            buf_st_f32(r_obs, (oidx + n) * 4u, active ? (float)(est[j] - t) : 0.0f);
+            buf_st_f64(r_rem, sidx * 8u, rem[j]);
+            buf_st_u32(r_de, sidx * 4u, (unsigned)((dep[j] & 0xffff) | (est[j] << 16)));
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const unsigned idx = (unsigned)p * 16u + q;
+            buf_st_f32(r_obs, (live && idx < k + 2u) ? (env * F + 2u * n + idx) * 4u : kOob, mo[p]);
+        }
+        buf_st_f64(r_acc, (live && q < 3u) ? env * 24u + q * 8u : kOob, do_reset ? 0.0 : acc);
+        {
+            v4u o0, o1;
+            o0.x = (unsigned)t; o0.y = (unsigned)cursor; o0.z = (unsigned)slot; o0.w = (unsigned)moer_day;
+            o1.x = (unsigned)n_sessions; o1.y = (unsigned)next_arrival; o1.z = (unsigned)status; o1.w = (unsigned)episodes;
+            const unsigned so = ((live || after_done) && q == 0u) ? env * 32u : kOob;
+            __builtin_amdgcn_raw_buffer_store_b128(o0, r_scal, (int)so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o1, r_scal, (int)so, 16, 0);
+        }
+    }
+}
+
+}  // namespace evc

@@ -187,11 +187,34 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
         ln.h = demand_cap_amps(r);
         if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; }
         __syncthreads();
-        solver_pass(P, L, ln, lane, L.z);
+
+        // (a) the screen of the streaming kernel may have been merely inconclusive: exact test of
+        //     the box clip; (b) only class caps (pod breakers) violated: closed-form water-filling
+        bool settled = false;
+        {
+            const double y0 = fmin(ln.b, ln.h);
+            unsigned cap_viol;
+            const unsigned long long vrows = exact_rows(P, L.net, lnet, lane, y0, cap_viol);
+            ln.y = y0;
+            if (vrows == 0ull) {
+                settled = true;
+            } else if ((vrows & ~(unsigned long long)P.simple_rows) == 0ull) {
+                double yw = y0;
+                for (int g = 0; g < G; g++)
+                    if ((cap_viol >> g) & 1u)
+                        yw = waterfill_class(lnet.gid == g, ln.b, ln.h, P.class_cap[g], yw);
+                unsigned cv2;
+                if (exact_rows(P, L.net, lnet, lane, yw, cv2) == 0ull) {
+                    ln.y = yw;
+                    settled = true;
+                }
+            }
+        }
+        if (!settled) solver_pass(P, L, ln, lane, L.z);
 
         double mu = 1e-3;
-        bool converged = false, last_ok = false;
-        for (int it = 0; it < kSolverMaxIter; it++) {
+        bool converged = settled, last_ok = false;
+        for (int it = 0; it < kSolverMaxIter && !settled; it++) {
             double g0, g1, nz, nw;
             row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
             const double rc = lane < m ? L.net.mag[lane] : 1.0;

@@ -46,7 +46,9 @@ def assert_step_parity(g, o, n, tag='', float_rtol=1e-9, check_debug=True):
         # solver outputs are snapped to a 2^-16 A grid (= 2^-21 normalised): the two solvers agree to
         # ~1e-10 A, so a value may land on adjacent grid points; everything else is far tighter
         np.testing.assert_allclose(g['projected'], o['projected'], rtol=0, atol=2.0 ** -21 + 1e-9, err_msg=tag)
-        assert np.mean(g['projected'] != o['projected']) < 1e-3, tag
+        # beyond last-bit differences (reciprocal-multiply vs divide of the demand cap) only the rare
+        # grid flips may remain
+        assert np.mean(np.abs(g['projected'] - o['projected']) > 1e-12) < 1e-3, tag
     # observation: est_departures (integers) bit-exact, float32 demands / moer / timestep exact
     # up to a float32 rounding flip of a 1e-13-different float64
     F = g['obs'].shape[1]
