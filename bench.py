@@ -114,12 +114,14 @@ def main():
     roofline = None
     if rank == 0:
         eng.enable_timing(True)
-        main_ms, slow_ms = [], []
+        main_ms, slow_ms, slow_cnt = [], [], []
         for i in range(args.kernel_timing_steps):
             step(ptrs[i % len(ptrs)])
             a, b = eng.last_step_ms()
             main_ms.append(a)
             slow_ms.append(b)
+            if project:
+                slow_cnt.append(eng.last_slow_count())
         eng.enable_timing(False)
         avg_main = float(np.mean(main_ms))
         avg_slow = float(np.mean(slow_ms))
@@ -138,6 +140,7 @@ def main():
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
                     'traffic': traffic, 'avg_kernel_ms': round(avg_main, 5),
                     'solver_kernel_ms': round(avg_slow, 5),
+                    'slow_queue_envs_per_step': (round(float(np.mean(slow_cnt)), 1) if slow_cnt else 0.0),
                     'algorithmic_bytes_per_launch': bytes_per_launch}
 
     # ---- CPU baseline: the oracle (scalar C restatement) on the host cores, bounded sample ----

@@ -200,6 +200,10 @@ int evc_read_metrics(evc_engine* e, double* out_host);
 
 /* Duration (ms) of the most recent evc_step's kernels measured with HIP events on the
  * engine's stream (enabled by evc_enable_timing(e,1)); used by bench.py's roofline leg. */
+/* Number of environments the most recent evc_step handed to the iterative/exact projection kernel
+ * (diagnostic; synchronises the stream). */
+int evc_last_slow_count(evc_engine* e, int32_t* count);
+
 int evc_enable_timing(evc_engine* e, int32_t on);
 int evc_last_step_ms(evc_engine* e, float* ms_main, float* ms_slow);
 

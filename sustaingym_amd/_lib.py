@@ -77,6 +77,7 @@ SIGNATURES = {
     'evc_set_breakdown': (_i32, [_vp, _vp]),
     'evc_clear_status': (_i32, [_vp]),
     'evc_read_metrics': (_i32, [_vp, _vp]),
+    'evc_last_slow_count': (_i32, [_vp, C.POINTER(_i32)]),
     'evc_enable_timing': (_i32, [_vp, _i32]),
     'evc_last_step_ms': (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }

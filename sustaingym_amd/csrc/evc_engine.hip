@@ -672,6 +672,14 @@ int evc_read_metrics(evc_engine* e, double* out_host) {
     return EVC_OK;
 }
 
+int evc_last_slow_count(evc_engine* e, int32_t* count) {
+    if (!e || !count) return fail(EVC_EINVAL, "null argument");
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(count, e->d_slow_count, sizeof(int), hipMemcpyDeviceToHost));
+    return EVC_OK;
+}
+
 int evc_enable_timing(evc_engine* e, int32_t on) {
     if (!e) return fail(EVC_EINVAL, "null engine");
     e->timing = on != 0;

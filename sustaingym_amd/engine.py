@@ -276,6 +276,11 @@ class StepEngine:
         return {'profit': out[0], 'carbon_cost': out[1], 'excess_charge': out[2],
                 'env_steps': out[3], 'episodes_finished': out[4], 'envs_with_status': out[5]}
 
+    def last_slow_count(self) -> int:
+        c = C.c_int32()
+        check(self.lib.evc_last_slow_count(self.handle, C.byref(c)), 'evc_last_slow_count')
+        return c.value
+
     def enable_timing(self, on: bool = True) -> None:
         check(self.lib.evc_enable_timing(self.handle, int(on)), 'evc_enable_timing')
 
