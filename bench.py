@@ -136,7 +136,7 @@ def main():
                 traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
-        roofline = {'bound': 'hbm', 'kernel': 'evc::step_kernel', 'achieved': round(achieved, 2),
+        roofline = {'bound': 'hbm', 'kernel': 'evc::step_kernel_quad', 'achieved': round(achieved, 2),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
                     'traffic': traffic, 'avg_kernel_ms': round(avg_main, 5),
                     'solver_kernel_ms': round(avg_slow, 5),

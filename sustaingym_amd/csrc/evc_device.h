@@ -97,7 +97,8 @@ struct Params {
     const float* moer_obs;         // [moer_days][289][37]    float32 (observation)
     const NetTables* tables;
     // slow-path queue (environments whose projection needs the iterative solver)
-    int* slow_count;               // [1]
+    int* slow_count;               // counter this step appends to
+    int* slow_count_next;          // counter the slow kernel clears for the next step
     int* slow_list;                // [N]
 };
 

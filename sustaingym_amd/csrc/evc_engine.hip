@@ -81,6 +81,7 @@ struct evc_engine {
     bool ev_valid = false, ev_slow = false;
     // host mirrors
     unsigned long long env_steps = 0;
+    int step_parity = 0;
     int step_grid = 0, solver_grid = 0, quad_grid = 0;
     bool use_quad = false;
 };
@@ -233,8 +234,12 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                            (const long long*)actions_dev, e->d_act_f32, count, bins);
         io.actions = e->d_act_f32;
     }
+    // The slow-queue counter is double-buffered: step s appends to counter[s & 1] and the slow
+    // kernel of step s clears counter[(s + 1) & 1] for the next step (no per-step memset kernel).
+    e->P.slow_count = e->d_slow_count + (e->step_parity & 1);
+    e->P.slow_count_next = e->d_slow_count + ((e->step_parity + 1) & 1);
+    e->step_parity ^= 1;
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
-    if (e->P.project) HIP_TRY(hipMemsetAsync(e->d_slow_count, 0, sizeof(int), e->stream));
     const int words = (e->P.G + 1) / 2;
     const bool dbg = out->pilots || out->rates || out->projected;
 #define EVC_LAUNCH_QUAD(W)                                                                         \
@@ -370,7 +375,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(dmalloc(&e->d_moer_hist, (size_t)moer_days * EVC_MOER_ROWS));
     A(dmalloc(&e->d_moer_obs, (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
     A(dmalloc(&e->d_tables, 1));
-    A(dmalloc(&e->d_slow_count, 1));
+    A(dmalloc(&e->d_slow_count, 2));
     A(dmalloc(&e->d_slow_list, N));
     A(dmalloc(&e->d_idbuf, 2 * N));
     A(dmalloc(&e->d_metrics, 8));
@@ -389,7 +394,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(hipMemset(e->d_slot_moer, 0, sizeof(int) * (size_t)bank_slots));
     A(hipMemset(e->d_moer_hist, 0, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS));
     A(hipMemset(e->d_moer_obs, 0, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
-    A(hipMemset(e->d_slow_count, 0, sizeof(int)));
+    A(hipMemset(e->d_slow_count, 0, 2 * sizeof(int)));
     A(hipMemcpy(e->d_tables, &T, sizeof(T), hipMemcpyHostToDevice));
     for (auto& ev : e->ev) A(hipEventCreate(&ev));
     if (err != hipSuccess) {
@@ -676,7 +681,11 @@ int evc_last_slow_count(evc_engine* e, int32_t* count) {
     if (!e || !count) return fail(EVC_EINVAL, "null argument");
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(count, e->d_slow_count, sizeof(int), hipMemcpyDeviceToHost));
+    int both[2];
+    HIP_TRY(hipMemcpy(both, e->d_slow_count, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    // the counter of the most recent step has already been cleared by its slow kernel only if the
+    // NEXT step ran; the one not selected for the next step holds the last count
+    *count = both[(e->step_parity + 1) & 1];
     return EVC_OK;
 }
 

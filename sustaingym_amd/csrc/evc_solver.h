@@ -168,6 +168,7 @@ template <int WORDS>
 __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
     __shared__ SolverLds L;
     const int count = rfl(*P.slow_count);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *P.slow_count_next = 0;   // double-buffered counter
     if ((int)blockIdx.x >= count) return;           // nothing queued for this workgroup
     stage_net(L.net, P);
     const int lane = threadIdx.x;

@@ -130,6 +130,19 @@ def test_edge_cases(caltech):
     eng.close()
 
 
+def test_odd_batch_sizes_and_wave_kernel(caltech, monkeypatch):
+    """N not a multiple of 4 (partially filled quad) and the one-environment-per-wavefront kernel
+    (EVC_KERNEL=wave, used for networks with more than 16 constraint rows)."""
+    n = caltech.num_stations
+    for N, kern in ((5, 'quad'), (7, 'wave'), (64, 'wave')):
+        monkeypatch.setenv('EVC_KERNEL', kern)
+        wl = make_workload(caltech, N, seed=23 + N, busy=(N == 64))
+        eng, bat = make_pair(caltech, N, wl, project=True)
+        rng = np.random.default_rng(N)
+        run_episode(eng, bat, n, 120, lambda t: rng.random((N, n), dtype=np.float32) ** 0.5, tag=f'N={N} {kern}')
+        eng.close()
+
+
 def test_device_tensor_path_matches_host_path(caltech):
     """evc_step with torch device tensors (async, on torch's stream) == evc_step_host."""
     import torch
