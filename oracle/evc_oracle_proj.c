@@ -280,12 +280,15 @@ int orc_project_action_impl(const orc_net* net, const double* action, const floa
      * rounding rule (env.py:373-378) sees them.  Exact optima that sit on a rounding boundary
      * (e.g. an 80 A pod shared by 4 EVs -> 20 A -> rint(2.5)) are thereby rounded the same way by
      * every solver that is within ~1e-6 A of the optimum; the reference's interior-point answer
-     * is itself only that accurate there. */
+     * is itself only that accurate there.  The grid is offset by sqrt(2)-1 grid
+     * steps so that its own midpoints are never dyadic / small-denominator rationals, which exact
+     * optima (e.g. (sum b - 80)/4) frequently are. */
     for (int i = 0; i < n; i++) {
         double y0 = b[i] < h[i] ? b[i] : h[i];
         double y = p->y[i];
         if (y != y0) {
-            y = rint(y * 65536.0) / 65536.0;
+            y = (rint(y * 65536.0 - 0.41421356237309515) + 0.41421356237309515) / 65536.0;
+            if (y < 0.0) y = 0.0;
             if (y > h[i]) y = h[i];
         }
         x_out[i] = y / 32.0;

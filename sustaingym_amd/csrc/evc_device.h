@@ -34,7 +34,8 @@ struct Consts {
     static constexpr double PROJ_TOL = 1e-10;              // rows within (1+tol) r count as satisfied
     static constexpr double PROJ_TOL_KKT = 1e-12;          // dual-gradient residual target of the solver
     static constexpr double PROJ_TOL_ACCEPT = 1e-9;        // accepted if the iteration budget runs out
-    static constexpr double TIE_SNAP = 65536.0;            // solver outputs snapped to 2^-16 A
+    static constexpr double TIE_SNAP = 65536.0;            // solver outputs snapped to a 2^-16 A grid
+    static constexpr double TIE_OFFSET = 0.41421356237309515;  // grid offset (in grid steps), sqrt(2)-1
 };
 
 constexpr int kWave = 64;
@@ -233,6 +234,13 @@ struct BitPlanes {
 // ------------------------------------------------------------------------------------------
 // per-station physics
 // ------------------------------------------------------------------------------------------
+
+// Tie snap of a solver-moved value: nearest point of the offset 2^-16 A grid,
+// kept inside [0, h].
+__device__ __forceinline__ double tie_snap(double y, double h) {
+    const double s = (rint(y * Consts::TIE_SNAP - Consts::TIE_OFFSET) + Consts::TIE_OFFSET) / Consts::TIE_SNAP;
+    return fmin(fmax(s, 0.0), h);
+}
 
 // env.py:366-378: normalised action -> EVSE-legal pilot (A).  y = 32 * action (float64).
 __device__ __forceinline__ double legal_pilot(double y, bool is_cc) {

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, EVC_MIN_WAVES) void step_kernel(Params P, Step
                         unsigned cv2;
                         if (exact_rows(P, net, ln, lane, yw, cv2) == 0ull) {
                             // tie snap of solver-moved values
-                            if (yw != y) yw = fmin(rint(yw * Consts::TIE_SNAP) / Consts::TIE_SNAP, h);
+                            if (yw != y) yw = tie_snap(yw, h);
                             y = yw;
                             solved = true;
                         }

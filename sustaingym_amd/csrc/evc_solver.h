@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
         // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
         // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
         double y = ln.y;
-        if (y != fmin(ln.b, ln.h)) y = fmin(rint(y * Consts::TIE_SNAP) / Consts::TIE_SNAP, ln.h);
+        if (y != fmin(ln.b, ln.h)) y = tie_snap(y, ln.h);
         finish_step<WORDS>(P, io, L.net, lnet, env, lane, y, clamped, cur.acc, false, r);
         __syncthreads();
     }
