@@ -60,6 +60,9 @@ extern "C" {
 /* action encodings for evc_step */
 #define EVC_ACTION_F32       0   /* float32[N][n] in [0,1]            (env.py:171-172)          */
 #define EVC_ACTION_DISCRETE  1   /* int64[N][n] in {0..bins-1}        (wrappers.py:43-45)       */
+#define EVC_ACTION_GREEDY    2   /* no action buffer: device-resident GreedyAlgorithm policy,
+                                    a = 1 where observation['demands'] > 0 else 0
+                                    (algorithms/evcharging/baselines.py:32-35)                   */
 
 /* per-environment status bits (replace the reference's exceptions / pdb) */
 #define EVC_STATUS_OCCUPIED     (1u << 0)  /* plug-in into an occupied EVSE (acnportal StationOccupiedError); session skipped */
@@ -109,6 +112,8 @@ typedef struct evc_step_out {
     double*  pilots;       /* [N][n]   pilot signals sent to the simulator (A), debug/parity       */
     double*  rates;        /* [N][n]   actual charging rates (A) = simulator.charging_rates[:,t-1] */
     double*  projected;    /* [N][n]   projected normalised action (env.py:220), debug/parity      */
+    double*  returns;      /* [N]      optional accumulator: returns[i] += reward (episode return of
+                                       BaseAlgorithm.run, algorithms/base.py:63-88); caller zeroes it */
 } evc_step_out;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
@@ -168,6 +173,14 @@ int evc_reset(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_
  * actions_dev: device [N][n]; action_kind EVC_ACTION_*; bins used for DISCRETE. */
 int evc_step(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
              const evc_step_out* out);
+
+/* Runs `steps` consecutive evc_step calls back to back on the engine's stream without returning to
+ * the host in between (device-resident policy or pre-staged actions): step i reads its actions at
+ * actions_dev + (i mod ring_len) * N * n elements (ignored for EVC_ACTION_GREEDY).  Outputs are those
+ * of the last step; out->returns accumulates over all steps.  Counterpart of the episode loop of
+ * BaseAlgorithm.run (algorithms/base.py:63-88). */
+int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
+                int32_t steps, int32_t ring_len, const evc_step_out* out);
 
 /* Host-buffer convenience variants (synchronous; staged through pinned memory).  Any
  * output pointer may be NULL. */

@@ -22,7 +22,7 @@ MOER_ROWS, MOER_COLS, EPISODE_STEPS = 289, 37, 288
 
 FLAG_PROJECT_ACTION = 1 << 0
 FLAG_AUTORESET = 1 << 1
-ACTION_F32, ACTION_DISCRETE = 0, 1
+ACTION_F32, ACTION_DISCRETE, ACTION_GREEDY = 0, 1, 2
 
 STATUS_OCCUPIED = 1 << 0
 STATUS_PROJ_NOCONV = 1 << 1
@@ -42,7 +42,7 @@ class NetworkDesc(C.Structure):
 class StepOut(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('terminated', C.c_void_p),
                 ('breakdown', C.c_void_p), ('final_obs', C.c_void_p), ('pilots', C.c_void_p),
-                ('rates', C.c_void_p), ('projected', C.c_void_p)]
+                ('rates', C.c_void_p), ('projected', C.c_void_p), ('returns', C.c_void_p)]
 
 
 class EngineLibraryError(RuntimeError):
@@ -67,6 +67,7 @@ SIGNATURES = {
     'evc_set_autoreset_stride': (_i32, [_vp, _i32]),
     'evc_reset': (_i32, [_vp, _vp, _i32, _vp, _vp]),
     'evc_step': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
+    'evc_rollout': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(StepOut)]),
     'evc_reset_host': (_i32, [_vp, _vp, _i32, _vp, _vp]),
     'evc_step_host': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
     'evc_get_env_scalars': (_i32, [_vp, _vp]),

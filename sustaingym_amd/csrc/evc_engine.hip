@@ -214,15 +214,17 @@ void compute_grids(evc_engine* e) {
 
 int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bins,
                 const evc_step_out* out) {
-    if (!actions_dev || !out || !out->obs || !out->reward || !out->terminated)
-        return fail(EVC_EINVAL, "evc_step: actions, out->obs, out->reward, out->terminated required");
-    if (action_kind != EVC_ACTION_F32 && action_kind != EVC_ACTION_DISCRETE)
+    if (!out || !out->obs || !out->reward || !out->terminated)
+        return fail(EVC_EINVAL, "evc_step: out->obs, out->reward, out->terminated required");
+    if (action_kind != EVC_ACTION_F32 && action_kind != EVC_ACTION_DISCRETE && action_kind != EVC_ACTION_GREEDY)
         return fail(EVC_EINVAL, "evc_step: unknown action_kind %d", action_kind);
+    if (!actions_dev && action_kind != EVC_ACTION_GREEDY)
+        return fail(EVC_EINVAL, "evc_step: actions required");
     if (action_kind == EVC_ACTION_DISCRETE && bins < 2)
         return fail(EVC_EINVAL, "evc_step: discrete actions need bins >= 2");
     StepIO io;
-    io.actions = actions_dev;
-    io.action_kind = EVC_ACTION_F32;
+    io.actions = action_kind == EVC_ACTION_GREEDY ? nullptr : actions_dev;
+    io.action_kind = action_kind == EVC_ACTION_GREEDY ? EVC_ACTION_GREEDY : EVC_ACTION_F32;
     io.bins = 0;
     io.out = *out;
     if (action_kind == EVC_ACTION_DISCRETE) {
@@ -555,6 +557,23 @@ int evc_step(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_
     return launch_step(e, actions_dev, action_kind, bins, out);
 }
 
+int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
+                int32_t steps, int32_t ring_len, const evc_step_out* out) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    if (steps < 1) return fail(EVC_EINVAL, "evc_rollout: steps must be >= 1");
+    if (action_kind != EVC_ACTION_GREEDY && (!actions_dev || ring_len < 1))
+        return fail(EVC_EINVAL, "evc_rollout: actions and ring_len >= 1 required");
+    if (int rc = bind(e)) return rc;
+    const size_t elem = action_kind == EVC_ACTION_DISCRETE ? 8 : 4;
+    const size_t stride = (size_t)e->P.N * e->P.n * elem;
+    for (int i = 0; i < steps; i++) {
+        const void* a = action_kind == EVC_ACTION_GREEDY
+            ? nullptr : (const void*)((const char*)actions_dev + (size_t)(i % ring_len) * stride);
+        if (int rc = launch_step(e, a, action_kind, bins, out)) return rc;
+    }
+    return EVC_OK;
+}
+
 int evc_reset_host(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_t* slots,
                    float* obs_host) {
     if (!e) return fail(EVC_EINVAL, "null engine");
@@ -569,18 +588,21 @@ int evc_reset_host(evc_engine* e, const int32_t* env_ids, int32_t count, const i
 
 int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, int32_t bins,
                   const evc_step_out* oh) {
-    if (!e || !actions_host || !oh) return fail(EVC_EINVAL, "evc_step_host: null argument");
+    if (!e || !oh || (!actions_host && action_kind != EVC_ACTION_GREEDY))
+        return fail(EVC_EINVAL, "evc_step_host: null argument");
     if (int rc = bind(e)) return rc;
     if (int rc = ensure_staging(e)) return rc;
     const size_t N = e->P.N, n = e->P.n, F = e->P.F;
     const size_t abytes = N * n * (action_kind == EVC_ACTION_DISCRETE ? 8 : 4);
-    HIP_TRY(hipMemcpyAsync(e->d_act, actions_host, abytes, hipMemcpyHostToDevice, e->stream));
+    if (actions_host)
+        HIP_TRY(hipMemcpyAsync(e->d_act, actions_host, abytes, hipMemcpyHostToDevice, e->stream));
     evc_step_out od;
     od.obs = e->d_obs; od.reward = e->d_reward; od.terminated = e->d_term;
     od.breakdown = e->d_breakdown; od.final_obs = e->d_final;
     od.pilots = oh->pilots ? e->d_pilots : nullptr;
     od.rates = oh->rates ? e->d_rates : nullptr;
     od.projected = oh->projected ? e->d_proj : nullptr;
+    od.returns = nullptr;
     if (int rc = launch_step(e, e->d_act, action_kind, bins, &od)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (oh->obs) HIP_TRY(hipMemcpy(oh->obs, e->d_obs, sizeof(float) * N * F, hipMemcpyDeviceToHost));

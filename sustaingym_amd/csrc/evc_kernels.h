@@ -92,7 +92,7 @@ __device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& i
     L.s1 = P.scal[2 * env + 1];
     L.rem = buf_ld_f64(row_rsrc(P.rem + (size_t)env * n, n * 8u), ul * 8u);
     L.de = (int)buf_ld_u32(row_rsrc(P.depest + (size_t)env * n, n * 4u), ul * 4u);
-    L.a = io.actions ? buf_ld_f32(row_rsrc((const float*)io.actions + (size_t)env * n, n * 4u), ul * 4u) : 0.0f;
+    L.a = (io.actions && io.action_kind == EVC_ACTION_F32) ? buf_ld_f32(row_rsrc((const float*)io.actions + (size_t)env * n, n * 4u), ul * 4u) : 0.0f;
     L.acc = buf_ld_f64(row_rsrc(P.acc + (size_t)env * 3, 24u), ul * 8u);
     if (ul >= n) L.de = kEmptyDep & 0xffff;          // lanes outside the network: empty EVSE
     return L;
@@ -108,8 +108,12 @@ __device__ __forceinline__ void unpack_env(const EnvLoads& L, EnvRegs& r) {
 
 // Normalised action clamped to [0,1] (the reference raises on out-of-range actions, SURVEY §8a
 // a2), as float64.
-__device__ __forceinline__ double unpack_action(const EnvLoads& L, bool& clamped) {
+__device__ __forceinline__ double unpack_action(const StepIO& io, const EnvLoads& L, bool& clamped) {
     float a = L.a;
+    if (io.action_kind == EVC_ACTION_GREEDY) {            // baselines.py:32-35 on the observation
+        const int dep = (int)(short)(L.de & 0xffff);
+        a = (dep != kEmptyDep && L.rem > Consts::FULLY_CHARGED_EPS) ? 1.0f : 0.0f;
+    }
     clamped = !(a >= 0.0f && a <= 1.0f);                 // also true for NaN
     a = fminf(fmaxf(a, 0.0f), 1.0f);                      // NaN -> 0
     return (double)a;
@@ -304,6 +308,7 @@ __device__ __forceinline__ void finish_step(const Params& P, const StepIO& io, c
     const double reward = profit - carbon - excess_charge;
     acc += (lane == 0) ? profit : (lane == 1 ? carbon : excess_charge);
     buf_st_f64(row_rsrc(io.out.reward + env, 8u), lane * 8u, reward);              // lane 0 only
+    if (io.out.returns && lane == 0) io.out.returns[env] += reward;
     buf_st_u8(row_rsrc(io.out.terminated + env, 1u), lane, done ? 1 : 0);            // lane 0 only
     if (io.out.breakdown) buf_st_f64(row_rsrc(io.out.breakdown + (size_t)env * 3, 24u), lane * 8u, acc);
     buf_st_f64(row_rsrc(P.acc + (size_t)env * 3, 24u), lane * 8u, (done && P.autoreset) ? 0.0 : acc);
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256, EVC_MIN_WAVES) void step_kernel(Params P, Step
         EnvRegs r;
         unpack_env(cur, r);
         bool clamped;
-        const double a = unpack_action(cur, clamped);
+        const double a = unpack_action(io, cur, clamped);
 #ifdef EVC_ABL_COPY
         {
             r.t += 1; r.rem += a;

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
         EnvRegs r;
         unpack_env(cur, r);
         bool clamped;
-        const double a = unpack_action(cur, clamped);
+        const double a = unpack_action(io, cur, clamped);
         ln.b = a * Consts::ACTION_SCALE_FACTOR;
         ln.h = demand_cap_amps(r);
         if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; }

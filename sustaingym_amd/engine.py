@@ -201,6 +201,44 @@ class StepEngine:
                 check(rc, 'evc_step')
         return step, out
 
+    def rollout(self, actions=None, steps: int = 288, policy: str | None = None, bins: int = 0,
+                accumulate_returns: bool = True):
+        """``steps`` consecutive steps without returning to Python (``evc_rollout``).
+
+        ``policy='greedy'``: device-resident GreedyAlgorithm (baselines.py:22-35), no action buffer.
+        Otherwise ``actions`` is a contiguous CUDA tensor ``[R, N, n]`` (float32, or int64 with
+        ``bins``) used as a ring.  Returns the device outputs of the last step plus ``'returns'``
+        (sum of rewards per environment over the rollout)."""
+        torch = self._torch()
+        self._bind_stream()
+        out = dict(self.device_outputs())
+        if accumulate_returns:
+            if 'returns' not in self._dev_out:
+                self._dev_out['returns_acc'] = torch.zeros((self.N,), dtype=torch.float64,
+                                                           device=torch.device('cuda', self.device))
+            acc = self._dev_out.setdefault('returns_acc', None)
+            acc.zero_()
+            out['returns'] = acc
+        out.pop('returns_acc', None)
+        so = self._step_out_struct(out, lambda t: C.c_void_p(t.data_ptr()))
+        if policy == 'greedy':
+            kind, ptr, ring = _lib.ACTION_GREEDY, None, 1
+        else:
+            assert actions is not None and actions.is_cuda and actions.is_contiguous()
+            assert actions.shape[1:] == (self.N, self.n)
+            kind = _lib.ACTION_DISCRETE if bins > 0 else _lib.ACTION_F32
+            ptr, ring = C.c_void_p(actions.data_ptr()), actions.shape[0]
+        check(self.lib.evc_rollout(self.handle, ptr, kind, bins, int(steps), int(ring), C.byref(so)),
+              'evc_rollout')
+        return out
+
+    def step_greedy(self, host: bool = True):
+        """One step of the device-resident greedy policy (host buffers)."""
+        out = self._host_buffers()
+        so = self._step_out_struct(out, _np_ptr)
+        check(self.lib.evc_step_host(self.handle, None, _lib.ACTION_GREEDY, 0, C.byref(so)), 'evc_step_host')
+        return out
+
     def _host_buffers(self) -> dict[str, np.ndarray]:
         if self._host_out is None:
             N, n, F = self.N, self.n, self.F

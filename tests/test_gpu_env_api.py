@@ -180,3 +180,51 @@ def test_vector_env_autoreset_and_single_env_equivalence():
     venv.close()
     for e in singles:
         e.close()
+
+
+def test_greedy_baseline_host_loop_vs_device_rollout():
+    """GreedyAlgorithm (baselines.py:22-35) three ways on real trace days: (1) the reference-style
+    Python episode loop over EVChargingEnv, (2) the oracle driven by the same policy, (3) the
+    device-resident policy through evc_rollout (whole episode in one C call)."""
+    import torch
+    from sustaingym_amd.algorithms import GreedyAlgorithm, RandomAlgorithm
+    from sustaingym_amd.engine import StepEngine
+    from sustaingym_amd.envs import _pad_table
+    gen = RealTraceGenerator('caltech', 'Summer 2019')
+    env = EVChargingEnv(gen)
+    res = GreedyAlgorithm(env).run([40, 41])
+    assert len(res['return']) == 2 and res['seed'] == [40, 41]
+    # (2) oracle with the same policy on day 40
+    g2 = RealTraceGenerator('caltech', 'Summer 2019')
+    g2.set_seed(40)
+    table = g2.get_event_table()
+    moer = g2.get_moer()
+    orc = ob.OracleEnv(ob.OracleNetwork(env.cn), 36, True)
+    o_obs = orc.reset(table.sessions, table.requested, moer)
+    ret = 0.0
+    for t in range(288):
+        a = np.where(o_obs[:54] > 0, 1, 0).astype(np.float32)
+        o_obs, r = orc.step(a)
+        ret += r.reward
+    assert abs(ret - res['return'][0]) <= 1e-9 * max(1.0, abs(ret))
+    assert abs(res['reward_breakdown'][0]['profit'] - r.breakdown[0]) <= 1e-9 * max(1.0, r.breakdown[0])
+    # (3) device-resident greedy over a batch: env 0 = day 40, env 1 = day 41
+    eng = StepEngine(env.cn, 2, project_action=True, bank_slots=2, max_sessions=256, moer_days=2)
+    ns, ss, rr, mm = [], [], [], []
+    for seed in (40, 41):
+        g2.set_seed(seed)
+        tb = g2.get_event_table()
+        s, r_ = _pad_table(tb, 256)
+        ns.append(len(tb)); ss.append(s); rr.append(r_); mm.append(g2.get_moer())
+    eng.upload_moer(np.stack(mm))
+    eng.upload_episodes(ns, np.stack(ss), np.stack(rr), [0, 1])
+    eng.reset()
+    out = eng.rollout(policy='greedy', steps=288)
+    torch.cuda.synchronize()
+    got = out['returns'].cpu().numpy()
+    assert np.allclose(got, res['return'], rtol=1e-9, atol=1e-12)
+    assert out['terminated'].cpu().numpy().all()
+    eng.close()
+    rnd = RandomAlgorithm(env, seed=0).run(1)
+    assert np.isfinite(rnd['return'][0])
+    env.close()
