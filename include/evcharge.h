@@ -182,6 +182,16 @@ int evc_step(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_
 int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
                 int32_t steps, int32_t ring_len, const evc_step_out* out);
 
+/* Per-agent observations of the multi-agent environment (multiagent_env.py:102-148) for the whole
+ * batch: out_dev[N][n][F].  Agent a of environment e receives the flattened observation obs_dev[e]
+ * in which, when delayed_obs_dev is not NULL (periods_delay > 0, documented semantics), the
+ * demands / est_departures of the OTHER agents are taken from delayed_obs_dev[e] (the observation
+ * periods_delay steps ago) while its own entries, the MOER part and the timestep are current.
+ * With delayed_obs_dev == NULL every agent row is a copy of obs_dev[e] (periods_delay = 0, and the
+ * reference's effective behaviour for any delay). */
+int evc_gather_agent_obs(evc_engine* e, const float* obs_dev, const float* delayed_obs_dev,
+                         float* out_dev);
+
 /* Host-buffer convenience variants (synchronous; staged through pinned memory).  Any
  * output pointer may be NULL. */
 int evc_reset_host(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_t* slots,

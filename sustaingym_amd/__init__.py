@@ -20,7 +20,7 @@ def __getattr__(name):
         from .engine import StepEngine
         return StepEngine
     if name in ('EVChargingEnv', 'MultiAgentEVChargingEnv', 'DiscreteActionWrapper',
-                'EVChargingVectorEnv', 'SB3VecEnv'):
+                'EVChargingVectorEnv', 'SB3VecEnv', 'MultiAgentEVChargingVectorEnv'):
         from . import envs
         return getattr(envs, name)
     raise AttributeError(name)

@@ -68,6 +68,7 @@ SIGNATURES = {
     'evc_reset': (_i32, [_vp, _vp, _i32, _vp, _vp]),
     'evc_step': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
     'evc_rollout': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(StepOut)]),
+    'evc_gather_agent_obs': (_i32, [_vp, _vp, _vp, _vp]),
     'evc_reset_host': (_i32, [_vp, _vp, _i32, _vp, _vp]),
     'evc_step_host': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
     'evc_get_env_scalars': (_i32, [_vp, _vp]),

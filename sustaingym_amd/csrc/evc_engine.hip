@@ -574,6 +574,17 @@ int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int
     return EVC_OK;
 }
 
+int evc_gather_agent_obs(evc_engine* e, const float* obs_dev, const float* delayed_obs_dev,
+                         float* out_dev) {
+    if (!e || !obs_dev || !out_dev) return fail(EVC_EINVAL, "evc_gather_agent_obs: null argument");
+    if (int rc = bind(e)) return rc;
+    int blocks = e->P.N < 4096 ? e->P.N : 4096;
+    hipLaunchKernelGGL(gather_agent_obs_kernel, dim3(blocks), dim3(256), 0, e->stream, obs_dev,
+                       delayed_obs_dev, out_dev, e->P.N, e->P.n, e->P.F);
+    HIP_TRY(hipGetLastError());
+    return EVC_OK;
+}
+
 int evc_reset_host(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_t* slots,
                    float* obs_host) {
     if (!e) return fail(EVC_EINVAL, "null engine");

@@ -514,6 +514,24 @@ __global__ __launch_bounds__(256) void discretize_kernel(const long long* in, fl
         out[i] = (float)in[i] / denom;
 }
 
+// Per-agent observation gather (multiagent_env.py:102-148), HBM-bound: one workgroup per
+// environment streams n rows of F floats (31.5 kB for Caltech) from two F-float source rows.
+__global__ __launch_bounds__(256) void gather_agent_obs_kernel(const float* __restrict__ obs,
+                                                               const float* __restrict__ delayed,
+                                                               float* __restrict__ out, int N, int n, int F) {
+    for (int env = blockIdx.x; env < N; env += gridDim.x) {
+        const float* cur = obs + (size_t)env * F;
+        const float* old = delayed ? delayed + (size_t)env * F : cur;
+        float* dst = out + (size_t)env * n * F;
+        const int total = n * F;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int a = i / F, f = i - a * F;
+            const bool others = f < 2 * n && f != a && f != n + a;   // another agent's demand / est_departure
+            dst[i] = others ? old[f] : cur[f];
+        }
+    }
+}
+
 // metrics reduction: sums of the running accumulators + status census.
 __global__ __launch_bounds__(256) void metrics_kernel(Params P, double* out) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, bad = 0.0, eps = 0.0;

@@ -232,6 +232,18 @@ class StepEngine:
               'evc_rollout')
         return out
 
+    def gather_agent_obs(self, obs, delayed=None, out=None):
+        """``[N, F]`` (+ optional delayed ``[N, F]``) -> materialised ``[N, n, F]`` per-agent
+        observations on the device (multiagent_env.py:102-148)."""
+        torch = self._torch()
+        self._bind_stream()
+        if out is None:
+            out = torch.empty((self.N, self.n, self.F), dtype=torch.float32, device=obs.device)
+        dptr = None if delayed is None else C.c_void_p(delayed.data_ptr())
+        check(self.lib.evc_gather_agent_obs(self.handle, C.c_void_p(obs.data_ptr()), dptr,
+                                            C.c_void_p(out.data_ptr())), 'evc_gather_agent_obs')
+        return out
+
     def step_greedy(self, host: bool = True):
         """One step of the device-resident greedy policy (host buffers)."""
         out = self._host_buffers()

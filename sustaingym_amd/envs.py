@@ -460,6 +460,67 @@ class EVChargingVectorEnv:
         return np.broadcast_to(flat_obs[:, None, :], (flat_obs.shape[0], n, flat_obs.shape[1]))
 
 
+class MultiAgentEVChargingVectorEnv:
+    """Batched form of :class:`MultiAgentEVChargingEnv` (BASELINE config 5: N environments x n
+    agents on the GPU).  ``step(actions[N, n])`` returns per-agent observations ``[N, n, F]``
+    (device tensor), rewards ``[N, n]`` (= reward / n for every agent, multiagent_env.py:186),
+    terminateds ``[N, n]``.  ``periods_delay = 0`` hands out a zero-copy broadcast view of the
+    flattened observation (every agent sees the same array, multiagent_env.py:114-117); with
+    ``delay_semantics='documented'`` and ``periods_delay > 0`` a HIP gather kernel builds each
+    agent's row from the current observation and the one ``periods_delay`` steps ago, which the
+    engine writes into a ring of observation buffers (no extra copies)."""
+
+    def __init__(self, data_generators, num_envs: int | None = None, periods_delay: int = 0,
+                 moer_forecast_steps: int = 36, project_action_in_env: bool = True,
+                 discrete_bins: int = -1, device: int = 0, delay_semantics: str = 'reference',
+                 materialize: bool = False):
+        assert delay_semantics in ('reference', 'documented')
+        self.venv = EVChargingVectorEnv(data_generators, num_envs, moer_forecast_steps,
+                                        project_action_in_env, discrete_bins, device, output='torch')
+        self.num_envs = self.venv.num_envs
+        self.possible_agents = self.venv.cn.station_ids[:]
+        self.num_agents = len(self.possible_agents)
+        self.periods_delay = periods_delay
+        self.delay = periods_delay if delay_semantics == 'documented' else 0
+        self.materialize = materialize or self.delay > 0
+        self._ring: list = []
+        self._pos = 0
+        self._agent_buf = None
+
+    def _agent_obs(self, flat, init: bool = False):
+        eng = self.venv._engine
+        if not self.materialize:
+            return self.venv.agent_observations(flat)
+        delayed = None
+        if self.delay > 0:
+            if init:
+                self._ring = [flat.clone() for _ in range(self.delay)]
+                self._pos = 0
+            delayed = self._ring[self._pos]
+        self._agent_buf = eng.gather_agent_obs(flat, delayed if not init else None, self._agent_buf)
+        if self.delay > 0 and not init:
+            self._ring[self._pos].copy_(flat)      # becomes the observation `delay` steps ago
+            self._pos = (self._pos + 1) % self.delay
+        return self._agent_buf
+
+    def reset(self, *, seed=None, options=None):
+        obs, info = self.venv.reset(seed=seed, options=options)
+        flat = self.venv._engine.device_outputs()['obs']
+        return self._agent_obs(flat, init=True), info
+
+    def step(self, actions):
+        """``actions``: CUDA tensor ``[N, n]`` (float32, or int64 for discrete bins)."""
+        obs, rew, term, trunc, info = self.venv.step(actions)
+        flat = self.venv._engine.device_outputs()['obs']
+        n = self.num_agents
+        agent_obs = self._agent_obs(flat)
+        rewards = (rew / n).unsqueeze(1).expand(-1, n)
+        return agent_obs, rewards, term.unsqueeze(1).expand(-1, n), trunc.unsqueeze(1).expand(-1, n), info
+
+    def close(self) -> None:
+        self.venv.close()
+
+
 class SB3VecEnv:
     """stable_baselines3 ``VecEnv`` protocol over :class:`EVChargingVectorEnv`
     (used like train_stable_baselines.py:275 uses SubprocVecEnv; policy ``MultiInputPolicy``)."""

@@ -228,3 +228,35 @@ def test_greedy_baseline_host_loop_vs_device_rollout():
     rnd = RandomAlgorithm(env, seed=0).run(1)
     assert np.isfinite(rnd['return'][0])
     env.close()
+
+
+@pytest.mark.parametrize('delay', [0, 3])
+def test_multiagent_vector_env_matches_single_multiagent_env(delay):
+    """BASELINE config 5 at test size: batched per-agent observations [N, n, F] from the HIP gather
+    kernel == the PettingZoo-style single environment (documented delay semantics)."""
+    import torch
+    from sustaingym_amd import MultiAgentEVChargingVectorEnv
+    N, n = 3, 54
+    mk = lambda i: GMMsTraceGenerator('caltech', 'Summer 2021')
+    venv = MultiAgentEVChargingVectorEnv(mk, num_envs=N, periods_delay=delay, delay_semantics='documented',
+                                         project_action_in_env=False, materialize=True)
+    obs, _ = venv.reset(seed=50)
+    singles = [MultiAgentEVChargingEnv(mk(i), periods_delay=delay, delay_semantics='documented',
+                                       project_action_in_env=False) for i in range(N)]
+    s_obs = [e.reset(seed=50 + i)[0] for i, e in enumerate(singles)]
+    assert obs.shape == (N, n, 146)
+    for i in range(N):
+        assert np.array_equal(obs[i, 0].cpu().numpy(), s_obs[i][singles[i].possible_agents[0]])
+    rng = np.random.default_rng(1)
+    for t in range(150):
+        a = rng.random((N, n), dtype=np.float32)
+        obs, rew, term, trunc, info = venv.step(torch.from_numpy(a).cuda())
+        got = obs.cpu().numpy()
+        for i, e in enumerate(singles):
+            so, sr, st, _, _ = e.step({ag: a[i, j:j + 1] for j, ag in enumerate(e.possible_agents)})
+            for j in (0, 17, 53):
+                assert np.array_equal(got[i, j], so[e.possible_agents[j]]), (t, i, j)
+            assert abs(float(rew[i, 0]) - sr[e.possible_agents[0]]) < 1e-15
+    venv.close()
+    for e in singles:
+        e.close()
