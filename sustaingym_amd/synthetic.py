@@ -62,16 +62,21 @@ def synthetic_episodes(num_episodes: int, num_stations: int, seed: int = 0,
     est = np.clip(departure + rng.integers(-12, 13, (P, E)), arrival + 1, 287)
 
     station = np.full((P, E), -1, dtype=np.int64)
-    station_dep = np.full((P, n), -1, dtype=np.int64)
+    # An EVSE is free for a new plug-in from the simulator pass in which its previous EV is
+    # unplugged: the EV plugs at pass max(arrival, 1) and its Unplug event is seen at pass
+    # max(departure, plug pass + 1) (acnportal pops events before processing them).  Plugging
+    # earlier would raise StationOccupiedError in acnportal.
+    free_pass = np.zeros((P, n), dtype=np.int64)
     rows = np.arange(P)
     for j in range(E):
-        avail = station_dep < arrival[:, j:j + 1]
+        plug_pass = np.maximum(arrival[:, j], 1)
+        avail = free_pass <= plug_pass[:, None]
         score = np.where(avail, rng.random((P, n)), -1.0)
         pick = np.argmax(score, axis=1)
         ok = valid[:, j] & avail[rows, pick]
         station[:, j] = np.where(ok, pick, -1)
-        upd = np.where(ok, np.maximum(departure[:, j], station_dep[rows, pick]), station_dep[rows, pick])
-        station_dep[rows, pick] = upd
+        release = np.maximum(departure[:, j], plug_pass + 1)
+        free_pass[rows, pick] = np.where(ok, release, free_pass[rows, pick])
     keep = station >= 0
     # compact kept sessions to the front, preserving arrival order
     order = np.argsort(~keep, axis=1, kind='stable')

@@ -111,6 +111,17 @@ def test_edge_cases(caltech):
     n = caltech.num_stations
     wl = make_workload(caltech, N, seed=13)
     wl['n_sessions'][:4] = 0                      # empty days
+    # env 4: a second EV arrives at an occupied EVSE (acnportal raises StationOccupiedError; we
+    # flag EVC_STATUS_OCCUPIED and skip that session); env 5: arrival 0 / departure 0 followed by
+    # an arrival at 1 on the same EVSE (both plug in pass 1 -> occupied as well)
+    wl['n_sessions'][4] = 2
+    wl['sessions'][4, 0] = (5, 50, 40, 2)
+    wl['sessions'][4, 1] = (10, 60, 55, 2)
+    wl['requested'][4, :2] = (20.0, 10.0)
+    wl['n_sessions'][5] = 2
+    wl['sessions'][5, 0] = (0, 0, 3, 7)
+    wl['sessions'][5, 1] = (1, 30, 25, 7)
+    wl['requested'][5, :2] = (5.0, 10.0)
     eng, bat = make_pair(caltech, N, wl, project=True)
     rng = np.random.default_rng(4)
 
@@ -122,6 +133,8 @@ def test_edge_cases(caltech):
     run_episode(eng, bat, n, 288, act, tag='edge')
     sc = eng.env_scalars()
     assert np.all(sc['status'] & _lib.STATUS_ACTION_CLAMPED)
+    occ = (sc['status'] & _lib.STATUS_OCCUPIED) != 0
+    assert occ[4] and occ[5] and occ.sum() == 2
     # step after termination: ignored + flagged, terminated stays set
     g = eng.step(np.zeros((N, n), np.float32))
     assert np.all(g['terminated'] == 1) and np.all(g['reward'] == 0)
