@@ -243,7 +243,8 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     e->step_parity ^= 1;
     if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
     const int words = (e->P.G + 1) / 2;
-    const bool dbg = out->pilots || out->rates || out->projected;
+    const bool dbg = out->pilots || out->rates || out->projected || out->returns ||
+                     action_kind == EVC_ACTION_GREEDY;
 #define EVC_LAUNCH_QUAD(W)                                                                         \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \

@@ -11,6 +11,10 @@
 // wave-per-environment kernel (evc_solver.h); they write nothing here.
 //
 // Requires m <= 16 (constraint row c is evaluated by lane c of every row).
+//
+// Template parameter DBG selects the generic instantiation (per-station debug outputs, the
+// device-resident greedy policy, the returns accumulator — all checked at run time); DBG = false
+// is the lean streaming kernel used by plain evc_step calls.
 #pragma once
 
 #include "evc_kernels.h"
@@ -63,7 +67,10 @@ __device__ __forceinline__ float quad_mag2_f32(const LdsNet& net, unsigned c, co
 }
 
 template <bool PROJECT, int WORDS, bool DBG>
-__global__ __launch_bounds__(256) void step_kernel_quad(Params P, StepIO io) {
+#ifndef EVC_QUAD_WAVES
+#define EVC_QUAD_WAVES 1
+#endif
+__global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P, StepIO io) {
     __shared__ LdsNet net;
     stage_net(net, P);
     const unsigned lane = threadIdx.x & 63u, q = lane & 15u, row = lane >> 4;
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) void step_kernel_quad(Params P, StepIO io) {
     // ---- buffer resources over whole arrays (lane supplies a 32-bit byte offset) ----
     const rsrc_t r_rem = row_rsrc(P.rem, N * n * 8u);
     const rsrc_t r_de = row_rsrc(P.depest, N * n * 4u);
-    const rsrc_t r_act = row_rsrc(io.actions, io.actions ? N * n * 4u : 0u);
+    const rsrc_t r_act = row_rsrc(io.actions, (!DBG || io.actions) ? N * n * 4u : 0u);
     const rsrc_t r_scal = row_rsrc(P.scal, N * 32u);
     const rsrc_t r_acc = row_rsrc(P.acc, N * 24u);
     const rsrc_t r_obs = row_rsrc(io.out.obs, N * F * 4u);
@@ -121,12 +128,14 @@ __global__ __launch_bounds__(256) void step_kernel_quad(Params P, StepIO io) {
             const unsigned idx = v ? env * n + (unsigned)j * 16u + q : kBadIdx;
             rem[j] = buf_ld_f64(r_rem, idx * 8u);
             const unsigned de = buf_ld_u32(r_de, idx * 4u);
+            const bool greedy = DBG && io.action_kind == EVC_ACTION_GREEDY;
+            float a_ld = 0.0f;
+            if (!greedy) a_ld = buf_ld_f32(r_act, idx * 4u);   // issued back to back with the other loads
             dep[j] = v ? (int)(short)(de & 0xffffu) : kEmptyDep;
             est[j] = (int)de >> 16;
-            if (io.action_kind == EVC_ACTION_GREEDY)          // baselines.py:32-35 on the observation
+            act[j] = a_ld;
+            if (greedy)                                         // baselines.py:32-35 on the observation
                 act[j] = (dep[j] != kEmptyDep && rem[j] > Consts::FULLY_CHARGED_EPS) ? 1.0f : 0.0f;
-            else
-                act[j] = buf_ld_f32(r_act, idx * 4u);
         }
         const double acc_in = buf_ld_f64(r_acc, (ev && q < 3u) ? env * 24u + q * 8u : kOob);
 
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256) void step_kernel_quad(Params P, StepIO io) {
         const double acc = acc_in + ((q == 0u) ? profit : (q == 1u ? carbon : excess_charge));
         const bool wr = live || after_done;           // rows that report reward / terminated
         buf_st_f64(r_rew, (wr && q == 0u) ? env * 8u : kOob, reward);
-        if (io.out.returns && live && q == 0u) io.out.returns[env] += reward;
+        if (DBG && io.out.returns && live && q == 0u) io.out.returns[env] += reward;
         buf_st_u8(r_term, (wr && q == 0u) ? env : kOob, (done || after_done) ? 1 : 0);
         buf_st_f64(r_bd, (live && q < 3u) ? env * 24u + q * 8u : kOob, acc);
         if (DBG) {                                                        // debug / parity outputs
