@@ -82,6 +82,7 @@ struct evc_engine {
     // host mirrors
     unsigned long long env_steps = 0;
     int step_parity = 0;
+    int num_cus = 256;
     int step_grid = 0, solver_grid = 0, quad_grid = 0;
     bool use_quad = false;
 };
@@ -200,8 +201,13 @@ void compute_grids(evc_engine* e) {
     if (blocks >= 8) blocks -= blocks % 8;
     e->step_grid = blocks;
     e->solver_grid = e->P.N < 1024 ? e->P.N : 1024;
+    // Streaming (quad) kernel: persistent-style grid of 4 workgroups per CU (= the 4 waves/SIMD its
+    // register footprint admits), every wave walks several quads.  Measured best on MI355X
+    // (tools/ab_caps.py): 1024 workgroups 30-32 us vs 4096 workgroups 35.6 us per step at N = 65 536.
     int qblocks = (((e->P.N + 3) / 4) + 3) / 4;          // quads per wave, 4 waves per workgroup
-    if (qblocks > cap) qblocks = cap;
+    int qcap = 4 * e->num_cus;
+    if (const char* s = getenv("EVC_GRID_CAP")) qcap = atoi(s) > 0 ? atoi(s) : qcap;
+    if (qblocks > qcap) qblocks = qcap;
     if (qblocks >= 8) qblocks -= qblocks % 8;
     if (qblocks < 1) qblocks = 1;
     e->quad_grid = qblocks;
@@ -342,12 +348,14 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (prop.warpSize != 64)
         return fail(EVC_ENODEV, "evc_create: device wavefront size %d != 64 (%s)", prop.warpSize, prop.gcnArchName);
 
     evc_engine* e = new evc_engine();
     e->device = device;
     e->flags = flags;
+    e->num_cus = cu_count;
     Params& P = e->P;
     P.N = num_envs;
     P.n = net->n_stations;

@@ -67,6 +67,9 @@ __device__ __forceinline__ float quad_mag2_f32(const LdsNet& net, unsigned c, co
 }
 
 template <bool PROJECT, int WORDS, bool DBG>
+#ifndef EVC_QUAD_PREFETCH
+#define EVC_QUAD_PREFETCH 0
+#endif
 #ifndef EVC_QUAD_WAVES
 #define EVC_QUAD_WAVES 1
 #endif
@@ -111,33 +114,60 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
 
     const unsigned nquads = (N + 3u) >> 2;
     EnvWalker walk((int)nquads, 4);            // XCD-aware walk over quads
+    struct QuadLoads {
+        v4u s0, s1;
+        double rem[kSlots];
+        unsigned de[kSlots];
+        float a[kSlots];
+        double acc;
+    };
+    auto issue = [&](int quad_) {
+        QuadLoads L;
+        const unsigned env_ = (unsigned)quad_ * 4u + row;
+        const bool ev_ = quad_ < walk.hi && env_ < N;
+        const unsigned soff = ev_ ? env_ * 32u : kOob;
+        L.s0 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 0, 0);
+        L.s1 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 16, 0);
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const bool v = ev_ && st_valid[j];
+            const unsigned idx = v ? env_ * n + (unsigned)j * 16u + q : kBadIdx;
+            L.rem[j] = buf_ld_f64(r_rem, idx * 8u);
+            L.de[j] = buf_ld_u32(r_de, idx * 4u);
+            const bool greedy = DBG && io.action_kind == EVC_ACTION_GREEDY;
+            L.a[j] = 0.0f;
+            if (!greedy) L.a[j] = buf_ld_f32(r_act, idx * 4u);
+        }
+        L.acc = buf_ld_f64(r_acc, (ev_ && q < 3u) ? env_ * 24u + q * 8u : kOob);
+        return L;
+    };
+#if EVC_QUAD_PREFETCH
+    QuadLoads nxt = issue(walk.first);
+#endif
     for (int quad = walk.first; quad < walk.hi; quad += walk.stride) {
         const unsigned env = (unsigned)quad * 4u + row;
         const bool ev = env < N;
-
-        // ---- loads: scalars (row-uniform, replicated), station rows, action row ----
-        const unsigned soff = ev ? env * 32u : kOob;
-        const v4u s0 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 0, 0);
-        const v4u s1 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 16, 0);
+#if EVC_QUAD_PREFETCH
+        const QuadLoads cur = nxt;
+        nxt = issue(quad + walk.stride);     // rows of the next quad are in flight while this one computes
+#else
+        const QuadLoads cur = issue(quad);
+#endif
+        const v4u s0 = cur.s0, s1 = cur.s1;
         double rem[kSlots];
         int dep[kSlots], est[kSlots];
         float act[kSlots];
 #pragma unroll
         for (int j = 0; j < kSlots; j++) {
             const bool v = ev && st_valid[j];
-            const unsigned idx = v ? env * n + (unsigned)j * 16u + q : kBadIdx;
-            rem[j] = buf_ld_f64(r_rem, idx * 8u);
-            const unsigned de = buf_ld_u32(r_de, idx * 4u);
-            const bool greedy = DBG && io.action_kind == EVC_ACTION_GREEDY;
-            float a_ld = 0.0f;
-            if (!greedy) a_ld = buf_ld_f32(r_act, idx * 4u);   // issued back to back with the other loads
-            dep[j] = v ? (int)(short)(de & 0xffffu) : kEmptyDep;
-            est[j] = (int)de >> 16;
-            act[j] = a_ld;
-            if (greedy)                                         // baselines.py:32-35 on the observation
+            rem[j] = cur.rem[j];
+            dep[j] = v ? (int)(short)(cur.de[j] & 0xffffu) : kEmptyDep;
+            est[j] = (int)cur.de[j] >> 16;
+            act[j] = cur.a[j];
+            if (DBG && io.action_kind == EVC_ACTION_GREEDY)     // baselines.py:32-35 on the observation
                 act[j] = (dep[j] != kEmptyDep && rem[j] > Consts::FULLY_CHARGED_EPS) ? 1.0f : 0.0f;
         }
-        const double acc_in = buf_ld_f64(r_acc, (ev && q < 3u) ? env * 24u + q * 8u : kOob);
+        const double acc_in = cur.acc;
 
         int t = (int)s0.x, cursor = (int)s0.y, slot = (int)s0.z, moer_day = (int)s0.w;
         int n_sessions = (int)s1.x, next_arrival = (int)s1.y, status = (int)s1.z, episodes = (int)s1.w;
