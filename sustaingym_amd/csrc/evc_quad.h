@@ -66,13 +66,100 @@ __device__ __forceinline__ float quad_mag2_f32(const LdsNet& net, unsigned c, co
     return re * re + im * im;
 }
 
-template <bool PROJECT, int WORDS, bool DBG>
+// Upper bound of the projected action (amps): min(32, demand_f32 / A_PERS_TO_KWH), env.py:188-189
+// with demands = previous float32 observation (env.py:218).  The quotient is a reciprocal multiply
+// + one fma correction (Markstein): correctly rounded like the divide, 3 instructions.
+__device__ __forceinline__ double quad_demand_cap(int dep, double rem) {
+    const bool active = (dep != kEmptyDep) && (rem > Consts::FULLY_CHARGED_EPS);
+    const double dm = (double)(float)rem;
+    const double q0 = dm * (1.0 / Consts::A_PERS_TO_KWH);
+    const double rr = fma(-q0, Consts::A_PERS_TO_KWH, dm);
+    const double cap = fmin(fma(rr, 1.0 / Consts::A_PERS_TO_KWH, q0), Consts::ACTION_SCALE_FACTOR);
+    return active ? cap : 0.0;
+}
+
+__device__ __forceinline__ double row_allreduce_min_f64(double v) {
+    v = fmin(v, dpp_f64<0x121, 0xf, false>(v));
+    v = fmin(v, dpp_f64<0x122, 0xf, false>(v));
+    v = fmin(v, dpp_f64<0x124, 0xf, false>(v));
+    v = fmin(v, dpp_f64<0x128, 0xf, false>(v));
+    return v;
+}
+
+// Exact float64 constraint rows of schedule y for the rows flagged `want` (row-uniform): returns,
+// for lane q < m, whether constraint row q is violated; cap_viol = classes above their cap.
+__device__ __forceinline__ bool quad_exact_rows(const Params& P, const LdsNet& net, unsigned q, unsigned m,
+                                                const int (&st_gid)[kSlots], const double (&y)[kSlots],
+                                                bool want, unsigned& cap_viol, double tol = Consts::PROJ_TOL) {
+    double re = 0.0, im = 0.0;
+    cap_viol = 0u;
+    for (int g = 0; g < P.G; g++) {
+        double part = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) part += (st_gid[j] == g) ? y[j] : 0.0;
+        const double S = row_allreduce_f64(part);
+        if (q < m) { re += net.Mre[g][q] * S; im += net.Mim[g][q] * S; }
+        if (S > P.class_cap[g] * (1.0 + tol)) cap_viol |= 1u << g;
+    }
+    return want && q < m && sqrt(re * re + im * im) > net.mag[q] * (1.0 + tol);
+}
+
+// Water-filling of class g inside each row flagged `on` (see waterfill_class in evc_kernels.h):
+// nu >= 0 with sum_{class g} clip(b - nu, 0, h) = cap; safeguarded Newton, row-local reductions.
+// b and h are recomputed from live registers (act, dep, rem) instead of being kept in arrays, and
+// y is updated in place, so this rare path adds no register pressure to the streaming kernel.
+__device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gid)[kSlots],
+                                               const float (&act)[kSlots], const int (&dep)[kSlots],
+                                               const double (&rem)[kSlots], double cap,
+                                               double (&y)[kSlots]) {
+    double nu = 0.0, lo = 0.0, hi = 64.0;
+    bool run = on;
+    for (int it = 0; it < 80 && __ballot(run) != 0ull; it++) {
+        double part = 0.0, nextbp = 1e300;
+        unsigned nfree = 0u;
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const bool in_g = st_gid[j] == g;
+            const double b = (double)act[j] * Consts::ACTION_SCALE_FACTOR;
+            const double h = quad_demand_cap(dep[j], rem[j]);
+            const double v = b - nu;
+            part += in_g ? fmin(fmax(v, 0.0), h) : 0.0;
+            nfree += (in_g && v > 0.0 && v <= h && h > 0.0) ? 1u : 0u;
+            nextbp = fmin(nextbp, (in_g && v > h) ? b - h : 1e300);
+        }
+        const double f = row_allreduce_f64(part) - cap;
+        const unsigned kfree = row_allreduce_u32(nfree);
+        const double bp = row_allreduce_min_f64(nextbp);
+        if (run) {
+            if (fabs(f) <= 1e-13 * cap) {
+                run = false;
+            } else {
+                if (f > 0.0) lo = nu; else hi = nu;
+                double nxt = (kfree > 0u) ? nu + f / (double)kfree : (f > 0.0 ? bp : 0.5 * (lo + hi));
+                if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+                nu = nxt;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        if (on && st_gid[j] == g) {
+            const double b = (double)act[j] * Consts::ACTION_SCALE_FACTOR;
+            const double h = quad_demand_cap(dep[j], rem[j]);
+            const double yw = fmin(fmax(b - nu, 0.0), h);
+            // tie snap of solver-moved values
+            y[j] = (yw != fmin(b, h)) ? tie_snap(yw, h) : yw;
+        }
+    }
+}
+
 #ifndef EVC_QUAD_PREFETCH
 #define EVC_QUAD_PREFETCH 0
 #endif
 #ifndef EVC_QUAD_WAVES
-#define EVC_QUAD_WAVES 1
+#define EVC_QUAD_WAVES 4
 #endif
+template <bool PROJECT, int WORDS, bool DBG>
 __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P, StepIO io) {
     __shared__ LdsNet net;
     stage_net(net, P);
@@ -83,7 +170,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
 
     // ---- per-lane, per-slot station constants ----
     bool st_valid[kSlots], st_cc[kSlots];
-    int st_word[kSlots], st_shift[kSlots];
+    int st_word[kSlots], st_shift[kSlots], st_gid[kSlots];
 #pragma unroll
     for (int j = 0; j < kSlots; j++) {
         const unsigned s = (unsigned)j * 16u + q;
@@ -94,6 +181,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
             if ((P.group_mask[g] >> s) & 1ull) gid = g;
         st_word[j] = gid >> 1;
         st_shift[j] = (gid & 1) << 4;
+        st_gid[j] = st_valid[j] ? gid : -1;
     }
 
     // ---- buffer resources over whole arrays (lane supplies a 32-bit byte offset) ----
@@ -187,45 +275,29 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
             if (idx == k + 1u) mo[p] = buf_ld_f32(r_ts, live ? (unsigned)t1 * 4u : kOob);
         }
 
-        // ---- action -> y (box clip), pilots, battery; accumulate reductions ----
+        // ---- action -> y (box clip of the projection) ----
         bool clamped = false;
         double y[kSlots];
         unsigned ywords[WORDS], pwords[WORDS];
 #pragma unroll
         for (int w = 0; w < WORDS; w++) { ywords[w] = 0u; pwords[w] = 0u; }
-        double amps_sum = 0.0;
-        double pilot[kSlots], amps[kSlots];      // kept only for the DBG outputs
 #pragma unroll
         for (int j = 0; j < kSlots; j++) {
             float a = act[j];
             clamped = clamped || (st_valid[j] && !(a >= 0.0f && a <= 1.0f));
             a = fminf(fmaxf(a, 0.0f), 1.0f);
+            act[j] = a;
             double yy = (double)a * Consts::ACTION_SCALE_FACTOR;        // env.py:366
             if (PROJECT) {
-                const bool active = (dep[j] != kEmptyDep) && (rem[j] > Consts::FULLY_CHARGED_EPS);
-                // demand / A_PERS_TO_KWH (env.py:188-189,218) as reciprocal multiply + one fma
-                // correction (Markstein): correctly rounded like the divide, 3 instructions
-                const double dm = (double)(float)rem[j];
-                const double q0 = dm * (1.0 / Consts::A_PERS_TO_KWH);
-                const double rr = fma(-q0, Consts::A_PERS_TO_KWH, dm);
-                const double cap = fmin(fma(rr, 1.0 / Consts::A_PERS_TO_KWH, q0), Consts::ACTION_SCALE_FACTOR);
-                yy = fmin(yy, active ? cap : 0.0);
+                yy = fmin(yy, quad_demand_cap(dep[j], rem[j]));
                 const unsigned qy = (unsigned)(int)ceil(yy * 8.0) << st_shift[j];
 #pragma unroll
                 for (int w = 0; w < WORDS; w++) ywords[w] += (st_word[j] == w) ? qy : 0u;
             }
             y[j] = yy;
-            const double pl = st_valid[j] ? legal_pilot(yy, st_cc[j]) : 0.0;
-            pilot[j] = pl;
-            const unsigned qp = (unsigned)(int)pl << st_shift[j];
-#pragma unroll
-            for (int w = 0; w < WORDS; w++) pwords[w] += (st_word[j] == w) ? qp : 0u;
-            const bool occupied = dep[j] != kEmptyDep;
-            amps[j] = charge_ev(occupied ? pl : 0.0, rem[j]);
-            amps_sum += amps[j];
         }
 
-        // ---- projection screen (PROJECT): inconclusive rows go to the slow kernel ----
+        // ---- projection screen (PROJECT) ----
         bool pilots_screened = false;
         if (PROJECT) {
 #pragma unroll
@@ -236,10 +308,50 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
                 maybe = !(mag2 < net.thr_y2[q]);
                 maybe_p = !(mag2 < net.thr_yp2[q]);
             }
-            const bool queue_me = live && row_any(maybe, row);
+            bool undecided = live && row_any(maybe, row);
             pilots_screened = !row_any(maybe_p, row);
-            if (queue_me && q == 0u) P.slow_list[atomicAdd(P.slow_count, 1)] = (int)env;
-            live = live && !queue_me;                 // queued rows write nothing here
+            if (__ballot(undecided) != 0ull) {
+                // Rare (wave-uniform branch): exact float64 rows for the undecided rows; class-cap
+                // (pod breaker) violations are projected in closed form by water-filling inside the
+                // row; anything else is queued for the slow kernel.
+                unsigned cap_viol;
+                bool hard = quad_exact_rows(P, net, q, m, st_gid, y, undecided, cap_viol);
+                bool nonsimple = row_any(hard && !((P.simple_rows >> q) & 1u), row);
+                bool anyviol = row_any(hard, row);
+                bool fill = undecided && anyviol && !nonsimple;
+                if (__ballot(fill) != 0ull) {
+                    // y is updated in place: rows that cannot be settled here are queued and the
+                    // slow kernel recomputes them from the stored state
+                    for (int g = 0; g < P.G; g++) {
+                        const bool do_g = fill && ((cap_viol >> g) & 1u);
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y);
+                    }
+                    unsigned cv2;
+                    // re-verify every row on the snapped values (snapping moves a class sum by < n 2^-17 A)
+                    const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, 1e-6), row);
+                    nonsimple = nonsimple || (fill && still);     // could not be settled here
+                    anyviol = anyviol && !(fill && !still);
+                }
+                const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel
+                if (queue_me && q == 0u) P.slow_list[atomicAdd(P.slow_count, 1)] = (int)env;
+                live = live && !queue_me;                 // queued rows write nothing here
+                pilots_screened = pilots_screened && !undecided;
+            }
+        }
+
+        // ---- pilots (env.py:366-378), battery charge, class sums of the pilots ----
+        double amps_sum = 0.0;
+        double pilot[kSlots], amps[kSlots];      // kept only for the DBG outputs
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const double pl = st_valid[j] ? legal_pilot(y[j], st_cc[j]) : 0.0;
+            pilot[j] = pl;
+            const unsigned qp = (unsigned)(int)pl << st_shift[j];
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) pwords[w] += (st_word[j] == w) ? qp : 0u;
+            const bool occupied = dep[j] != kEmptyDep;
+            amps[j] = charge_ev(occupied ? pl : 0.0, rem[j]);
+            amps_sum += amps[j];
         }
 
         // ---- reductions inside the row ----
