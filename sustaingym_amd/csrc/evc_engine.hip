@@ -200,7 +200,9 @@ void compute_grids(evc_engine* e) {
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks -= blocks % 8;
     e->step_grid = blocks;
-    e->solver_grid = e->P.N < 1024 ? e->P.N : 1024;
+    int scap = 256;          // the slow queue is nearly always empty or tiny; queued envs are looped over
+    if (const char* s = getenv("EVC_SOLVER_GRID")) scap = atoi(s) > 0 ? atoi(s) : scap;
+    e->solver_grid = e->P.N < scap ? e->P.N : scap;
     // Streaming (quad) kernel: persistent-style grid of 4 workgroups per CU (= the 4 waves/SIMD its
     // register footprint admits), every wave walks several quads.  Measured best on MI355X
     // (tools/ab_caps.py): 1024 workgroups 30-32 us vs 4096 workgroups 35.6 us per step at N = 65 536.
