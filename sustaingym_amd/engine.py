@@ -60,6 +60,7 @@ class StepEngine:
         self.handle = handle
         self._dev_out: dict[str, Any] | None = None
         self._host_out: dict[str, np.ndarray] | None = None
+        self._returns = None
 
     # ------------------------------------------------------------------ lifecycle
     def close(self) -> None:
@@ -213,13 +214,11 @@ class StepEngine:
         self._bind_stream()
         out = dict(self.device_outputs())
         if accumulate_returns:
-            if 'returns' not in self._dev_out:
-                self._dev_out['returns_acc'] = torch.zeros((self.N,), dtype=torch.float64,
-                                                           device=torch.device('cuda', self.device))
-            acc = self._dev_out.setdefault('returns_acc', None)
-            acc.zero_()
-            out['returns'] = acc
-        out.pop('returns_acc', None)
+            if self._returns is None:
+                self._returns = torch.zeros((self.N,), dtype=torch.float64,
+                                            device=torch.device('cuda', self.device))
+            self._returns.zero_()
+            out['returns'] = self._returns
         so = self._step_out_struct(out, lambda t: C.c_void_p(t.data_ptr()))
         if policy == 'greedy':
             kind, ptr, ring = _lib.ACTION_GREEDY, None, 1

@@ -260,3 +260,29 @@ def test_multiagent_vector_env_matches_single_multiagent_env(delay):
     venv.close()
     for e in singles:
         e.close()
+
+
+def test_vector_env_torch_output_stays_on_device():
+    """output='torch': actions in, observations / rewards out as device tensors (no host copies)."""
+    import torch
+    N = 8
+    venv = EVChargingVectorEnv(lambda i: GMMsTraceGenerator('jpl', 'Fall 2019'), num_envs=N, output='torch')
+    host = EVChargingVectorEnv(lambda i: GMMsTraceGenerator('jpl', 'Fall 2019'), num_envs=N)
+    obs, info = venv.reset(seed=9)
+    hobs, _ = host.reset(seed=9)
+    assert obs['demands'].is_cuda and obs['demands'].shape == (N, 52)
+    rng = np.random.default_rng(2)
+    for t in range(288):
+        a = rng.random((N, 52), dtype=np.float32)
+        obs, rew, term, trunc, info = venv.step(torch.from_numpy(a).cuda())
+        hobs, hrew, hterm, _, hinfo = host.step(a)
+        assert rew.is_cuda and term.dtype == torch.bool
+        assert np.array_equal(rew.cpu().numpy(), hrew) and np.array_equal(term.cpu().numpy(), hterm)
+        # after the autoreset at step 288 the two vector envs play different (unseeded) episodes,
+        # like two reference envs would after reset(seed=None); compare the terminal observation
+        src, hsrc = (obs, hobs) if t < 287 else (info['final_observation'], hinfo['final_observation'])
+        for key in hobs:
+            assert np.array_equal(src[key].cpu().numpy(), hsrc[key]), (key, t)
+    assert bool(term.all())
+    venv.close()
+    host.close()

@@ -16,7 +16,20 @@ import numpy as np
 sys.path.insert(0, '/root/repo')
 sys.path.insert(0, '/root/repo/tools')
 from sustaingym_amd.network import caltech_acn, jpl_acn, station_groups  # noqa: E402
-from proj_proto import scipy_ref  # noqa: E402
+from scipy.optimize import minimize  # noqa: E402
+
+
+def scipy_ref(net, b, h):
+    At = net.a_tilde()
+    r = net.magnitudes
+    cons = [{'type': 'ineq', 'fun': (lambda y, c=c: r[c] ** 2 - np.abs(At[c] @ y) ** 2),
+             'jac': (lambda y, c=c: -2 * (np.real(At[c] @ y) * np.real(At[c]) + np.imag(At[c] @ y) * np.imag(At[c])))}
+            for c in range(len(r))]
+    res = minimize(lambda y: 0.5 * np.sum((y - b) ** 2), np.minimum(b, h) * 0.5, jac=lambda y: y - b,
+                   bounds=[(0.0, hi) for hi in h], constraints=cons, method='SLSQP',
+                   options={'ftol': 1e-16, 'maxiter': 500})
+    return res.x, res
+
 
 
 def group_tables(net):
