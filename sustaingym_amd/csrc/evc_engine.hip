@@ -215,7 +215,9 @@ void compute_grids(evc_engine* e) {
     // the 4-environments-per-wavefront kernel evaluates constraint row c in lane c of a 16-lane
     // row and addresses whole arrays with 32-bit byte offsets
     const char* kk = getenv("EVC_KERNEL");
-    const bool fits32 = (double)e->P.N * e->P.F * 4.0 < 2.0e9 && (double)e->P.N * e->P.n * 8.0 < 2.0e9;
+    const bool fits32 = (double)e->P.N * e->P.F * 4.0 < 2.0e9 && (double)e->P.N * e->P.n * 8.0 < 2.0e9 &&
+                        (double)e->P.bank_slots * e->P.max_sessions * 8.0 < 2.0e9 &&
+                        (double)e->P.moer_days * EVC_MOER_ROWS * EVC_MOER_COLS * 4.0 < 2.0e9;
     e->use_quad = e->P.m <= 16 && fits32 && !(kk && strcmp(kk, "wave") == 0);
 }
 
