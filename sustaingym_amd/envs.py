@@ -22,7 +22,7 @@ import numpy as np
 
 from . import spaces
 from .engine import StepEngine
-from .event_generation import AbstractTraceGenerator, EventTable
+from .event_generation import AbstractTraceGenerator, BatchedGMMTraceGenerator, EventTable
 from .network import site_str_to_site
 
 try:  # pragma: no cover
@@ -317,6 +317,10 @@ class EVChargingVectorEnv:
     double-buffered in the engine's bank: while environment i plays the episode in slot i the next
     one already sits in slot i+N, and the kernel-side autoreset flips between the two.
 
+    For large N pass one :class:`BatchedGMMTraceGenerator` (plus ``num_envs``): all episodes of a
+    boundary are drawn in one vectorised call on a worker thread while the GPU plays the current
+    episodes (~50 us per episode instead of ~2 ms through N per-environment generators).
+
     ``output='numpy'`` (default) returns host arrays (SB3 / RLLib); ``'torch'`` takes and returns
     device tensors without leaving the GPU."""
 
@@ -325,7 +329,11 @@ class EVChargingVectorEnv:
                  project_action_in_env: bool = True, discrete_bins: int = -1, device: int = 0,
                  output: str = 'numpy', max_sessions: int = 128):
         assert output in ('numpy', 'torch')
-        if callable(data_generators):
+        self._batched = data_generators if isinstance(data_generators, BatchedGMMTraceGenerator) else None
+        if self._batched is not None:
+            assert num_envs is not None, 'num_envs is required with a BatchedGMMTraceGenerator'
+            gens = [self._batched] * num_envs
+        elif callable(data_generators):
             assert num_envs is not None
             gens = [data_generators(i) for i in range(num_envs)]
         else:
@@ -361,12 +369,53 @@ class EVChargingVectorEnv:
         self._max_profit = np.zeros(2 * N)            # per bank slot
         self._cur_slot = np.arange(N)                 # slot each env is playing
         self._episodes = np.zeros(N, dtype=np.int64)
+        self._steps_in_episode = 0                    # all environments run in lock-step (288 steps)
+        self._pending = None                          # (future, slots): background refill, batched mode
+        self._pool = None
         self.closed = False
 
     # -- episode staging ------------------------------------------------------------------
+    def _upload_runs(self, slots, ns, sess, req, day) -> None:
+        order = np.argsort(slots)
+        s_sorted = slots[order]
+        start = 0
+        for end in range(1, len(slots) + 1):           # contiguous runs of slots upload in one call each
+            if end == len(slots) or s_sorted[end] != s_sorted[end - 1] + 1:
+                sel = order[start:end]
+                self._engine.upload_episodes(ns[sel], sess[sel], req[sel], day[sel], int(s_sorted[start]))
+                start = end
+
+    def _stage_batched(self, slots: np.ndarray, background: bool = False) -> None:
+        """One vectorised draw for all ``slots``; with ``background`` the sampling runs on a worker
+        thread while the GPU keeps stepping and is uploaded by :meth:`_drain` (at the latest before
+        the step that ends the current episodes)."""
+        def work():
+            return self._batched.sample_episodes(len(slots), self._stride)
+        if background:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=1)
+            self._pending = (self._pool.submit(work), slots)
+        else:
+            self._finish_batched(slots, work())
+
+    def _finish_batched(self, slots, drawn) -> None:
+        ns, sess, req, day, mp = drawn
+        self._max_profit[slots] = mp
+        self._upload_runs(slots, ns, sess, req, day)
+
+    def _drain(self, force: bool) -> None:
+        if self._pending is not None and (force or self._pending[0].done()):
+            fut, slots = self._pending
+            self._pending = None
+            self._finish_batched(slots, fut.result())
+
     def _stage(self, env_ids: np.ndarray, slots: np.ndarray, seeds) -> None:
         from ._lib import SESSION_DTYPE
         cnt = len(env_ids)
+        if self._batched is not None:
+            self._stage_batched(np.asarray(slots))
+            return
         ns = np.zeros(cnt, np.int32)
         sess = np.zeros((cnt, self._stride), dtype=SESSION_DTYPE)
         req = np.zeros((cnt, self._stride))
@@ -379,15 +428,7 @@ class EVChargingVectorEnv:
             sess[j], req[j] = _pad_table(table, self._stride)
             day[j] = (g.day - self._day0).days         # MOER of the advanced day (env.py:321-323)
             self._max_profit[slots[j]] = table.max_profit()
-        order = np.argsort(slots)
-        # contiguous runs of slots upload in one call each
-        s_sorted = slots[order]
-        start = 0
-        for end in range(1, cnt + 1):
-            if end == cnt or s_sorted[end] != s_sorted[end - 1] + 1:
-                sel = order[start:end]
-                self._engine.upload_episodes(ns[sel], sess[sel], req[sel], day[sel], int(s_sorted[start]))
-                start = end
+        self._upload_runs(np.asarray(slots), ns, sess, req, day)
 
     def _wrap_obs(self, flat):
         return {key: flat[:, sl] for key, sl in self._slices.items()}
@@ -402,6 +443,10 @@ class EVChargingVectorEnv:
         else:
             seeds = list(seed)
         ids = np.arange(N)
+        self._drain(force=True)
+        if self._batched is not None and seed is not None:
+            self._batched.set_seed(int(seed) if np.isscalar(seed) else int(seeds[0]))
+        self._steps_in_episode = 0
         self._stage(ids, ids, seeds)                  # current episodes -> slots [0, N)
         self._stage(ids, ids + N, [None] * N)         # next episodes   -> slots [N, 2N)
         self._cur_slot = ids.copy()
@@ -426,6 +471,8 @@ class EVChargingVectorEnv:
     def step(self, actions):
         N = self.num_envs
         bins = self.discrete_bins if self.discrete_bins > 0 else 0
+        self._steps_in_episode += 1
+        self._drain(force=self._steps_in_episode >= 288)      # next episodes must be in the bank now
         if self.output == 'numpy':
             out = self._engine.step(np.ascontiguousarray(actions), bins=bins)
             term = out['terminated'].astype(bool)
@@ -441,12 +488,18 @@ class EVChargingVectorEnv:
             vacated = self._cur_slot[ids].copy()
             self._cur_slot[ids] = (vacated + N) % (2 * N)     # kernel autoreset: slot + stride
             self._episodes[ids] += 1
-            self._stage(ids, vacated, [None] * len(ids))      # refill the vacated slots
+            self._steps_in_episode = 0
+            if self._batched is not None:
+                self._stage_batched(vacated, background=True)  # overlaps the next episode's steps
+            else:
+                self._stage(ids, vacated, [None] * len(ids))  # refill the vacated slots
         truncated = np.zeros(N, dtype=bool) if self.output == 'numpy' else term.new_zeros(N)
         return self._wrap_obs(out['obs']), out['reward'], term, truncated, self._infos(out, done_mask)
 
     def close(self) -> None:
         if not self.closed:
+            if self._pool is not None:
+                self._pool.shutdown(wait=True)
             self._engine.close()
             self.closed = True
 
