@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 1
+#define EVC_ABI_VERSION 2
 
 #define EVC_MAX_STATIONS     64   /* one gfx950 wavefront per environment            */
 #define EVC_MAX_CONSTRAINTS  32   /* rows of ChargingNetwork.constraint_matrix       */
@@ -48,6 +48,9 @@ extern "C" {
 #define EVC_MOER_COLS        37
 #define EVC_EPISODE_STEPS    288  /* env.py:124 max_timestep                         */
 #define EVC_MAX_SESSIONS     256  /* per episode (real traces <= 81, GMM <= 84)      */
+#define EVC_MAX_GMM_COMPONENTS 32  /* mixture components of the episode generator     */
+#define EVC_MAX_DAILY_COUNTS 512   /* empirical sessions-per-day table                */
+#define EVC_MAX_GENERATED_SESSIONS 128 /* per generated episode                        */
 
 /* EVSE kinds (env.py:371-378; acnportal AeroVironment / ClipperCreek FiniteRatesEVSE) */
 #define EVC_EVSE_AV 0   /* allowable pilots {0} U {6,7,...,32} A */
@@ -159,6 +162,42 @@ int evc_upload_episodes(evc_engine* e, int32_t first_slot, int32_t count, int32_
 
 /* Autoreset walks the bank: next_slot = (slot + stride) mod bank_slots. */
 int evc_set_autoreset_stride(evc_engine* e, int32_t stride);
+
+/* ---- on-device episode generation (GMMsTraceGenerator on the GPU) ------------------ */
+
+/* The model GMMsTraceGenerator samples from (event_generation.py:372-515): a K-component
+ * Gaussian mixture over (arrival, departure, estimated departure [fractions of a day],
+ * requested energy / 100 kWh), the empirical daily session counts, and the historical usage
+ * count of every EVSE.  Host arrays, copied by evc_upload_gmm. */
+typedef struct evc_gmm_desc {
+    int32_t         n_components;         /* K <= EVC_MAX_GMM_COMPONENTS                  */
+    int32_t         n_counts;             /* <= EVC_MAX_DAILY_COUNTS                      */
+    int32_t         num_days;             /* episode day ~ U{0..num_days-1} (:117-119); <= moer_days */
+    int32_t         reserved;
+    const double*   cum_weights;          /* [K] cumulative mixture weights, last = 1     */
+    const double*   means;                /* [K][4]                                       */
+    const double*   chol;                 /* [K][4][4] lower Cholesky factor of each covariance, row-major */
+    const int32_t*  daily_counts;         /* [n_counts] (:479)                            */
+    const uint32_t* station_usage;        /* [n] (:497), sum < 2^31                       */
+    double          requested_energy_cap; /* kWh, <= 100 (:169-170)                       */
+} evc_gmm_desc;
+int evc_upload_gmm(evc_engine* e, const evc_gmm_desc* gmm);
+
+/* Generates `count` episodes into bank slots [first_slot, first_slot+count) on the engine's
+ * stream (asynchronous, no host work): GMMsTraceGenerator._create_events
+ * (event_generation.py:465-515) with the reference's numpy/sklearn random streams replaced by
+ * the counter-based stream Philox4x32-10(key = seed, counter = (index, purpose, episode)),
+ * episode = first_episode + i.  The episodes follow the reference generator's distribution;
+ * they are bit-reproducible from (seed, episode) and independent of launch geometry. */
+int evc_generate_episodes(evc_engine* e, int32_t first_slot, int32_t count, uint64_t seed,
+                          uint64_t first_episode);
+
+/* Reads bank slots back to the host (any argument may be NULL): n_sessions[count],
+ * sessions[count][stride], requested_kwh[count][stride], moer_day[count], and
+ * max_profit[count] (env.py:422-429; computed for uploaded and generated episodes alike). */
+int evc_download_episodes(evc_engine* e, int32_t first_slot, int32_t count, int32_t stride,
+                          int32_t* n_sessions, evc_session* sessions, double* requested_kwh,
+                          int32_t* moer_day, double* max_profit);
 
 /* ---- hot path ---------------------------------------------------------------------- */
 

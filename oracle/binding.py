@@ -30,10 +30,17 @@ class StepResult(C.Structure):
                 ('status', C.c_uint32)]
 
 
+class GmmDesc(C.Structure):
+    _fields_ = [('n_components', C.c_int32), ('n_counts', C.c_int32), ('num_days', C.c_int32),
+                ('reserved', C.c_int32), ('cum_weights', C.c_void_p), ('means', C.c_void_p),
+                ('chol', C.c_void_p), ('daily_counts', C.c_void_p), ('station_usage', C.c_void_p),
+                ('requested_energy_cap', C.c_double)]
+
+
 def build(force: bool = False) -> str:
     """Compiles the oracle with gcc (oracle/Makefile)."""
     srcs = [os.path.join(_HERE, f) for f in
-            ('evc_oracle.c', 'evc_oracle_proj.c', 'evc_oracle.h', 'evc_oracle_priv.h')]
+            ('evc_oracle.c', 'evc_oracle_proj.c', 'evc_oracle_gen.c', 'evc_oracle.h', 'evc_oracle_priv.h')]
     stale = (not os.path.exists(_LIB_PATH) or
              any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs))
     if force or stale:
@@ -74,6 +81,13 @@ def lib() -> C.CDLL:
         L.orc_batch_reset.argtypes = [vp, vp, vp]
         L.orc_batch_step.argtypes = [vp, vp, vp, i32, i32, i32, i32] + [vp] * 9
         L.orc_max_threads.restype = i32
+        L.orc_philox4x32.argtypes = [C.c_uint32] * 6 + [vp]
+        L.orc_gen_log.restype = C.c_double
+        L.orc_gen_log.argtypes = [C.c_double]
+        L.orc_gen_normal.restype = C.c_double
+        L.orc_gen_normal.argtypes = [C.c_double]
+        L.orc_generate_episode.restype = i32
+        L.orc_generate_episode.argtypes = [C.POINTER(GmmDesc), i32, C.c_uint64, C.c_uint64, i32, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -232,6 +246,45 @@ class OracleBatch:
                              _p(out['breakdown']), _p(out['final_obs']), _p(out.get('pilots')),
                              _p(out.get('rates')), _p(out.get('projected')), _p(out['status']))
         return out
+
+
+def philox4x32(counter, key) -> np.ndarray:
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32(*[int(c) for c in counter], int(key[0]), int(key[1]), _p(out))
+    return out
+
+
+class OracleGenerator:
+    """orc_generate_episode over GMM tables (dict of arrays: cum_weights, means, chol,
+    daily_counts, station_usage, num_days, requested_energy_cap)."""
+
+    def __init__(self, tables: dict, n_stations: int):
+        self.n = n_stations
+        self._keep = {
+            'cum_weights': np.ascontiguousarray(tables['cum_weights'], dtype=np.float64),
+            'means': np.ascontiguousarray(tables['means'], dtype=np.float64),
+            'chol': np.ascontiguousarray(tables['chol'], dtype=np.float64),
+            'daily_counts': np.ascontiguousarray(tables['daily_counts'], dtype=np.int32),
+            'station_usage': np.ascontiguousarray(tables['station_usage'], dtype=np.uint32),
+        }
+        k = self._keep
+        self.desc = GmmDesc(len(k['cum_weights']), len(k['daily_counts']), int(tables['num_days']), 0,
+                            k['cum_weights'].ctypes.data, k['means'].ctypes.data, k['chol'].ctypes.data,
+                            k['daily_counts'].ctypes.data, k['station_usage'].ctypes.data,
+                            float(tables['requested_energy_cap']))
+
+    def episodes(self, seed: int, first_episode: int, count: int, max_sessions: int = 128):
+        ns = np.zeros(count, np.int32)
+        sess = np.zeros((count, max_sessions), dtype=SESSION_DTYPE)
+        req = np.zeros((count, max_sessions))
+        day = np.zeros(count, np.int32)
+        mp = np.zeros(count)
+        L = lib()
+        for i in range(count):
+            ns[i] = L.orc_generate_episode(C.byref(self.desc), self.n, seed, first_episode + i, max_sessions,
+                                           sess[i].ctypes.data, req[i].ctypes.data,
+                                           day[i:].ctypes.data, mp[i:].ctypes.data)
+        return ns, sess, req, day, mp
 
 
 def max_threads() -> int:

@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SUSTAINGYM_AMD_LIB', os.path.join(_PKG, 'libevcharge_hip.so'))
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'evcharge.h')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_STATIONS, MAX_CONSTRAINTS, MAX_GROUPS, MAX_SESSIONS = 64, 32, 16, 256
 MOER_ROWS, MOER_COLS, EPISODE_STEPS = 289, 37, 288
 
@@ -37,6 +37,13 @@ class NetworkDesc(C.Structure):
     _fields_ = [('n_stations', C.c_int32), ('n_constraints', C.c_int32),
                 ('constraint_matrix', C.c_void_p), ('phase_angles_deg', C.c_void_p),
                 ('magnitudes', C.c_void_p), ('evse_kind', C.c_void_p)]
+
+
+class GmmDesc(C.Structure):
+    _fields_ = [('n_components', C.c_int32), ('n_counts', C.c_int32), ('num_days', C.c_int32),
+                ('reserved', C.c_int32), ('cum_weights', C.c_void_p), ('means', C.c_void_p),
+                ('chol', C.c_void_p), ('daily_counts', C.c_void_p), ('station_usage', C.c_void_p),
+                ('requested_energy_cap', C.c_double)]
 
 
 class StepOut(C.Structure):
@@ -65,6 +72,9 @@ SIGNATURES = {
     'evc_upload_moer': (_i32, [_vp, _i32, _i32, _vp]),
     'evc_upload_episodes': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     'evc_set_autoreset_stride': (_i32, [_vp, _i32]),
+    'evc_upload_gmm': (_i32, [_vp, C.POINTER(GmmDesc)]),
+    'evc_generate_episodes': (_i32, [_vp, _i32, _i32, C.c_uint64, C.c_uint64]),
+    'evc_download_episodes': (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'evc_reset': (_i32, [_vp, _vp, _i32, _vp, _vp]),
     'evc_step': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
     'evc_rollout': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(StepOut)]),

@@ -12,6 +12,7 @@
 
 #include "evc_solver.h"
 #include "evc_quad.h"
+#include "evc_gen.h"
 
 using namespace evc;
 
@@ -63,6 +64,8 @@ struct evc_engine {
     int* d_slow_list = nullptr;
     int* d_idbuf = nullptr;       // reset ids/slots staging [2N]
     double* d_metrics = nullptr;  // [8]
+    double* d_maxprofit = nullptr;  // [bank_slots] env.py:422-429 of the episode in each slot
+    GenTables* d_gen = nullptr;     // episode-generator model (evc_upload_gmm)
     // device staging for the *_host entry points
     float* d_act_f32 = nullptr;   // float32 actions produced by discretize_kernel
     void* d_act = nullptr;        // N*n*8 bytes
@@ -98,7 +101,7 @@ void free_all(evc_engine* e) {
                     e->d_nsess, e->d_slot_moer, e->d_moer_hist, e->d_moer_obs, e->d_tables,
                     e->d_slow_count, e->d_slow_list, e->d_idbuf, e->d_metrics, e->d_act, e->d_act_f32, e->d_obs,
                     e->d_reward, e->d_term, e->d_breakdown, e->d_final, e->d_pilots, e->d_rates,
-                    e->d_proj};
+                    e->d_proj, e->d_maxprofit, e->d_gen};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ev : e->ev)
@@ -386,6 +389,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(dmalloc(&e->d_requested, (size_t)bank_slots * max_sessions));
     A(dmalloc(&e->d_nsess, (size_t)bank_slots));
     A(dmalloc(&e->d_slot_moer, (size_t)bank_slots));
+    A(dmalloc(&e->d_maxprofit, (size_t)bank_slots));
     A(dmalloc(&e->d_moer_hist, (size_t)moer_days * EVC_MOER_ROWS));
     A(dmalloc(&e->d_moer_obs, (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
     A(dmalloc(&e->d_tables, 1));
@@ -406,6 +410,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(hipMemset(e->d_requested, 0, sizeof(double) * (size_t)bank_slots * max_sessions));
     A(hipMemset(e->d_nsess, 0, sizeof(int) * (size_t)bank_slots));
     A(hipMemset(e->d_slot_moer, 0, sizeof(int) * (size_t)bank_slots));
+    A(hipMemset(e->d_maxprofit, 0, sizeof(double) * (size_t)bank_slots));
     A(hipMemset(e->d_moer_hist, 0, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS));
     A(hipMemset(e->d_moer_obs, 0, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
     A(hipMemset(e->d_slow_count, 0, 2 * sizeof(int)));
@@ -494,6 +499,7 @@ int evc_upload_episodes(evc_engine* e, int32_t first_slot, int32_t count, int32_
     if (stride < 1) return fail(EVC_EINVAL, "evc_upload_episodes: stride must be >= 1");
     std::vector<evc_session> s((size_t)count * P.max_sessions);
     std::vector<double> rq((size_t)count * P.max_sessions, 0.0);
+    std::vector<double> profit((size_t)count, 0.0);
     memset(s.data(), 0, sizeof(evc_session) * s.size());
     for (int i = 0; i < count; i++) {
         const int ns = n_sessions[i];
@@ -516,6 +522,8 @@ int evc_upload_episodes(evc_engine* e, int32_t first_slot, int32_t count, int32_
                             "(requested_energy_cap > battery capacity is unsupported)", i, j, r);
             s[(size_t)i * P.max_sessions + j] = x;
             rq[(size_t)i * P.max_sessions + j] = r;
+            profit[i] += std::fmin(r, (double)(x.departure - x.arrival) * 32.0 * Consts::A_PERS_TO_KWH) *
+                         Consts::MARGINAL_PROFIT_PER_KWH;                              // env.py:422-429
         }
     }
     if (int rc = bind(e)) return rc;
@@ -526,6 +534,85 @@ int evc_upload_episodes(evc_engine* e, int32_t first_slot, int32_t count, int32_
                       sizeof(double) * rq.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_nsess + first_slot, n_sessions, sizeof(int) * count, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_slot_moer + first_slot, moer_day, sizeof(int) * count, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_maxprofit + first_slot, profit.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return EVC_OK;
+}
+
+int evc_upload_gmm(evc_engine* e, const evc_gmm_desc* g) {
+    if (!e || !g || !g->cum_weights || !g->means || !g->chol || !g->daily_counts || !g->station_usage)
+        return fail(EVC_EINVAL, "evc_upload_gmm: null argument");
+    if (g->n_components < 1 || g->n_components > EVC_MAX_GMM_COMPONENTS)
+        return fail(EVC_EINVAL, "evc_upload_gmm: %d components outside [1,%d]", g->n_components, EVC_MAX_GMM_COMPONENTS);
+    if (g->n_counts < 1 || g->n_counts > EVC_MAX_DAILY_COUNTS)
+        return fail(EVC_EINVAL, "evc_upload_gmm: %d daily counts outside [1,%d]", g->n_counts, EVC_MAX_DAILY_COUNTS);
+    if (g->num_days < 1 || g->num_days > e->P.moer_days)
+        return fail(EVC_EINVAL, "evc_upload_gmm: num_days %d outside [1, moer_days = %d]", g->num_days, e->P.moer_days);
+    if (!(g->requested_energy_cap >= 0.0) || g->requested_energy_cap > Consts::BATTERY_CAPACITY)
+        return fail(EVC_EINVAL, "evc_upload_gmm: requested_energy_cap %g outside [0,100] kWh", g->requested_energy_cap);
+    GenTables T;
+    memset(&T, 0, sizeof(T));
+    T.K = g->n_components; T.n_counts = g->n_counts; T.num_days = g->num_days;
+    T.cap = g->requested_energy_cap;
+    for (int k = 0; k < T.K; k++) {
+        T.cum[k] = g->cum_weights[k];
+        if (!(T.cum[k] >= (k ? T.cum[k - 1] : 0.0)) || T.cum[k] > 1.0)
+            return fail(EVC_EINVAL, "evc_upload_gmm: cum_weights must be non-decreasing in [0,1]");
+    }
+    memcpy(T.means, g->means, sizeof(double) * 4 * T.K);
+    memcpy(T.chol, g->chol, sizeof(double) * 16 * T.K);
+    for (int i = 0; i < T.n_counts; i++) {
+        if (g->daily_counts[i] < 0) return fail(EVC_EINVAL, "evc_upload_gmm: negative daily count");
+        T.counts[i] = g->daily_counts[i];
+    }
+    unsigned long long total = 0;
+    for (int i = 0; i < e->P.n; i++) { T.usage[i] = g->station_usage[i]; total += T.usage[i]; }
+    if (total >= (1ull << 31)) return fail(EVC_EINVAL, "evc_upload_gmm: station usage counts sum to >= 2^31");
+    if (int rc = bind(e)) return rc;
+    if (!e->d_gen) HIP_TRY(hipMalloc(&e->d_gen, sizeof(GenTables)));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_gen, &T, sizeof(T), hipMemcpyHostToDevice));
+    return EVC_OK;
+}
+
+int evc_generate_episodes(evc_engine* e, int32_t first_slot, int32_t count, uint64_t seed,
+                          uint64_t first_episode) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    if (!e->d_gen) return fail(EVC_ESTATE, "evc_generate_episodes: no model uploaded (evc_upload_gmm)");
+    const Params& P = e->P;
+    if (first_slot < 0 || count < 1 || first_slot + count > P.bank_slots)
+        return fail(EVC_EINVAL, "evc_generate_episodes: slots [%d,%d) outside bank of %d", first_slot,
+                    first_slot + count, P.bank_slots);
+    if (int rc = bind(e)) return rc;
+    const int grid = std::min(count, e->num_cus * 32);
+    hipLaunchKernelGGL(generate_kernel, dim3(grid), dim3(64), 0, e->stream, e->d_gen, P.n, P.max_sessions,
+                       e->d_sessions, e->d_requested, e->d_nsess, e->d_slot_moer, e->d_maxprofit, first_slot,
+                       count, (unsigned long long)seed, (unsigned long long)first_episode);
+    HIP_TRY(hipGetLastError());
+    return EVC_OK;
+}
+
+int evc_download_episodes(evc_engine* e, int32_t first_slot, int32_t count, int32_t stride,
+                          int32_t* n_sessions, evc_session* sessions, double* requested,
+                          int32_t* moer_day, double* max_profit) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    const Params& P = e->P;
+    if (first_slot < 0 || count < 1 || first_slot + count > P.bank_slots)
+        return fail(EVC_EINVAL, "evc_download_episodes: slots [%d,%d) outside bank of %d", first_slot,
+                    first_slot + count, P.bank_slots);
+    if ((sessions || requested) && stride < P.max_sessions)
+        return fail(EVC_EINVAL, "evc_download_episodes: stride %d < max_sessions %d", stride, P.max_sessions);
+    if (int rc = bind(e)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const size_t S = (size_t)P.max_sessions;
+    if (n_sessions) HIP_TRY(hipMemcpy(n_sessions, e->d_nsess + first_slot, sizeof(int) * count, hipMemcpyDeviceToHost));
+    if (moer_day) HIP_TRY(hipMemcpy(moer_day, e->d_slot_moer + first_slot, sizeof(int) * count, hipMemcpyDeviceToHost));
+    if (max_profit) HIP_TRY(hipMemcpy(max_profit, e->d_maxprofit + first_slot, sizeof(double) * count, hipMemcpyDeviceToHost));
+    if (sessions)
+        HIP_TRY(hipMemcpy2D(sessions, sizeof(evc_session) * (size_t)stride, e->d_sessions + first_slot * S,
+                            sizeof(evc_session) * S, sizeof(evc_session) * S, count, hipMemcpyDeviceToHost));
+    if (requested)
+        HIP_TRY(hipMemcpy2D(requested, sizeof(double) * (size_t)stride, e->d_requested + first_slot * S,
+                            sizeof(double) * S, sizeof(double) * S, count, hipMemcpyDeviceToHost));
     return EVC_OK;
 }
 

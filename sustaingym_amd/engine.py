@@ -102,6 +102,48 @@ class StepEngine:
                                            _np_ptr(sessions), _np_ptr(requested), _np_ptr(moer_day)),
               'evc_upload_episodes')
 
+    def upload_gmm(self, tables: dict) -> None:
+        """Model of the on-device episode generator (``event_generation.gmm_device_tables``)."""
+        keep = {
+            'cum_weights': np.ascontiguousarray(tables['cum_weights'], dtype=np.float64),
+            'means': np.ascontiguousarray(tables['means'], dtype=np.float64),
+            'chol': np.ascontiguousarray(tables['chol'], dtype=np.float64),
+            'daily_counts': np.ascontiguousarray(tables['daily_counts'], dtype=np.int32),
+            'station_usage': np.ascontiguousarray(tables['station_usage'], dtype=np.uint32),
+        }
+        K = len(keep['cum_weights'])
+        assert keep['means'].shape == (K, 4) and keep['chol'].shape == (K, 4, 4)
+        assert len(keep['station_usage']) == self.n
+        desc = _lib.GmmDesc(K, len(keep['daily_counts']), int(tables['num_days']), 0,
+                            keep['cum_weights'].ctypes.data, keep['means'].ctypes.data, keep['chol'].ctypes.data,
+                            keep['daily_counts'].ctypes.data, keep['station_usage'].ctypes.data,
+                            float(tables['requested_energy_cap']))
+        check(self.lib.evc_upload_gmm(self.handle, C.byref(desc)), 'evc_upload_gmm')
+
+    def generate_episodes(self, first_slot: int, count: int, seed: int, first_episode: int) -> None:
+        """Fills bank slots ``[first_slot, first_slot+count)`` on the GPU (asynchronous on the
+        current stream): episode ``first_episode + i`` of the Philox stream keyed by ``seed``."""
+        import sys
+        if 'torch' in sys.modules and sys.modules['torch'].cuda.is_available():
+            self._bind_stream()                  # otherwise the engine's own (host-path) stream
+        check(self.lib.evc_generate_episodes(self.handle, int(first_slot), int(count),
+                                             C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                             C.c_uint64(int(first_episode))), 'evc_generate_episodes')
+
+    def download_episodes(self, first_slot: int, count: int, tables: bool = True):
+        """Bank slots back on the host: ``(n_sessions, sessions, requested, moer_day, max_profit)``
+        (``sessions``/``requested`` are ``None`` when ``tables`` is false)."""
+        ns = np.zeros(count, np.int32)
+        day = np.zeros(count, np.int32)
+        mp = np.zeros(count, np.float64)
+        sess = np.zeros((count, self.max_sessions), dtype=SESSION_DTYPE) if tables else None
+        req = np.zeros((count, self.max_sessions), dtype=np.float64) if tables else None
+        check(self.lib.evc_download_episodes(self.handle, int(first_slot), count, self.max_sessions,
+                                             _np_ptr(ns), None if sess is None else _np_ptr(sess),
+                                             None if req is None else _np_ptr(req), _np_ptr(day), _np_ptr(mp)),
+              'evc_download_episodes')
+        return ns, sess, req, day, mp
+
     def set_autoreset_stride(self, stride: int) -> None:
         check(self.lib.evc_set_autoreset_stride(self.handle, int(stride)), 'evc_set_autoreset_stride')
         self.autoreset_stride = int(stride) % self.bank_slots

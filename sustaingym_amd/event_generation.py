@@ -402,36 +402,55 @@ class BatchedGMMTraceGenerator:
             return tuple(np.concatenate([p[j] for p in parts]) for j in range(5))
         return self._sample_block(count, stride, self.rng)
 
-    def _draw(self, shape: tuple[int, int], rng) -> np.ndarray:
+    def _draw(self, shape: tuple[int, int], rng):
         comp = rng.choice(len(self._g.weights_), size=shape, p=self._g.weights_)
         z = rng.standard_normal(shape + (4,))
         x = np.empty_like(z)
         for c in range(len(self._g.weights_)):
             sel = comp == c
             x[sel] = self._g.means_[c] + z[sel] @ self._chol[c].T
-        return x
+        return comp, x
 
     def _sample_block(self, count: int, stride: int, rng):
         g, n = self._g, self.num_stations
         want = rng.choice(g.cnt, size=count).astype(np.int64)                       # :479
         want = np.minimum(want, stride)
-        B = int(max(8, np.ceil(1.6 * max(1, want.max()))))
-        x = self._draw((count, B), rng)
-        ok = (0 <= x[..., 0]) & (x[..., 1] < 1) & (x[..., 2] < 1) & (x[..., 3] >= 0)    # :441-444
-        t = np.floor(MINS_IN_DAY * x[..., :3] / self.TIME_STEP_DURATION)             # :447-449
-        ok &= (t[..., 0] < t[..., 1]) & (t[..., 0] < t[..., 2])                       # :452-455
-        rank = np.cumsum(ok, axis=1)
-        ok &= rank <= want[:, None]                                                   # first n valid draws
-        short = ok.sum(axis=1) < want                                                  # rare: too many rejected
-        if short.any():
-            want = np.minimum(want, ok.sum(axis=1))
-        arrival = np.where(ok, t[..., 0], 1e9)
-        order = np.argsort(arrival, axis=1, kind='stable')[:, :stride]               # :490
+        E = int(max(1, want.max())) if count else 1
+        # :416-463 incl. the reference's surplus cut: every round draws int(1.2 n) samples that
+        # sklearn returns stacked in component order, and only the first n accepted are kept.
+        m = (want * (1 + 0.2)).astype(np.int64)
+        acc = np.zeros((4, count, E))
+        have = np.zeros(count, dtype=np.int64)
+        K = len(g.weights_)
+        for _ in range(16):
+            idx = np.nonzero(have < want)[0]
+            if len(idx) == 0:
+                break
+            mi = m[idx]
+            B = int(mi.max())
+            comp, x = self._draw((len(idx), B), rng)
+            inr = np.arange(B)[None, :] < mi[:, None]
+            order = np.argsort(np.where(inr, comp, K), axis=1, kind='stable')
+            x = np.take_along_axis(x, order[..., None], 1)
+            ok = np.take_along_axis(inr, order, 1)
+            ok &= (0 <= x[..., 0]) & (x[..., 1] < 1) & (x[..., 2] < 1) & (x[..., 3] >= 0)    # :441-444
+            t = np.floor(MINS_IN_DAY * x[..., :3] / self.TIME_STEP_DURATION)             # :447-449
+            ok &= (t[..., 0] < t[..., 1]) & (t[..., 0] < t[..., 2])                       # :452-455
+            pos = have[idx, None] + np.cumsum(ok, axis=1) - 1
+            ok &= pos < want[idx, None]                                                   # first n accepted
+            r, c = np.nonzero(ok)
+            for k in range(3):
+                acc[k, idx[r], pos[r, c]] = t[r, c, k]
+            acc[3, idx[r], pos[r, c]] = np.clip(x[r, c, 3] * REQ_ENERGY_SCALE, 0, self.requested_energy_cap)  # :458,486
+            have[idx] += ok.sum(axis=1)
+        want = have
+        filled = np.arange(E)[None, :] < want[:, None]
+        order = np.argsort(np.where(filled, acc[0], 1e9), axis=1, kind='stable')       # :490
         take = lambda a: np.take_along_axis(a, order, 1)
-        arr = take(np.where(ok, t[..., 0], 0)).astype(np.int64)
-        dep = take(np.where(ok, t[..., 1], 0)).astype(np.int64)
-        est = take(np.where(ok, t[..., 2], 0)).astype(np.int64)
-        req = take(np.clip(x[..., 3] * REQ_ENERGY_SCALE, 0, self.requested_energy_cap))   # :458,486
+        arr = take(acc[0]).astype(np.int64)
+        dep = take(acc[1]).astype(np.int64)
+        est = take(acc[2]).astype(np.int64)
+        req = take(acc[3])
         E = arr.shape[1]
         live = np.arange(E)[None, :] < want[:, None]
         station = np.full((count, E), -1, dtype=np.int64)
@@ -466,3 +485,22 @@ class BatchedGMMTraceGenerator:
         dur = (sess['departure'].astype(np.int64) - sess['arrival'].astype(np.int64))[:, :E]
         max_profit = np.where(mask, np.minimum(reqo[:, :E], dur * 32 * a_pers) * 0.03, 0.0).sum(axis=1)
         return n_sessions, sess, reqo, day, max_profit
+
+
+def gmm_device_tables(site: str, date_period, requested_energy_cap: float = 100) -> dict:
+    """Tables of the on-device episode generator (include/evcharge.h ``evc_gmm_desc``): the
+    packaged GMM of the period with cumulative weights and Cholesky factors precomputed, the
+    empirical daily session counts (event_generation.py:479) and the integer EVSE usage counts
+    (:497)."""
+    g = GMMsTraceGenerator(site, date_period, requested_energy_cap=requested_energy_cap)
+    cum = np.cumsum(g.weights_)
+    cum[-1] = 1.0
+    usage = np.asarray(g.station_usage)
+    assert np.all(usage == np.round(usage)) and usage.min() >= 0 and usage.sum() < 2 ** 31
+    return {
+        'cum_weights': cum, 'means': np.ascontiguousarray(g.means_, dtype=np.float64),
+        'chol': np.ascontiguousarray(np.linalg.cholesky(g.covariances_)),
+        'daily_counts': np.asarray(g.cnt, dtype=np.int32),
+        'station_usage': usage.astype(np.uint32), 'num_days': g.num_days_in_date_range,
+        'requested_energy_cap': float(requested_energy_cap),
+    }
