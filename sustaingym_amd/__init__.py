@@ -4,15 +4,17 @@ Public surface (mirrors ``sustaingym.envs.evcharging``):
 
     EVChargingEnv, MultiAgentEVChargingEnv, DiscreteActionWrapper      (reference API)
     EVChargingVectorEnv, SB3VecEnv                                      (batched API)
-    RealTraceGenerator, GMMsTraceGenerator, BatchedGMMTraceGenerator    (episode generators)
+    RealTraceGenerator, GMMsTraceGenerator, BatchedGMMTraceGenerator,
+    DeviceGMMTraceGenerator                                             (episode generators)
     StepEngine                                                          (C-ABI handle)
 
 The HIP library is loaded lazily (``sustaingym_amd._lib.load``); importing the package does not
 need a GPU, constructing an environment does.
 """
 from .network import ChargingNetwork, caltech_acn, jpl_acn, site_str_to_site  # noqa: F401
-from .event_generation import (AbstractTraceGenerator, BatchedGMMTraceGenerator, EventTable,  # noqa: F401
-                               GMMsTraceGenerator, MOERLoader, RealTraceGenerator)
+from .event_generation import (AbstractTraceGenerator, BatchedGMMTraceGenerator,  # noqa: F401
+                               DeviceGMMTraceGenerator, EventTable, GMMsTraceGenerator, MOERLoader,
+                               RealTraceGenerator)
 
 
 def __getattr__(name):

@@ -22,7 +22,8 @@ import numpy as np
 
 from . import spaces
 from .engine import StepEngine
-from .event_generation import AbstractTraceGenerator, BatchedGMMTraceGenerator, EventTable
+from .event_generation import (AbstractTraceGenerator, BatchedGMMTraceGenerator, DeviceGMMTraceGenerator,
+                               EventTable)
 from .network import site_str_to_site
 
 try:  # pragma: no cover
@@ -319,7 +320,9 @@ class EVChargingVectorEnv:
 
     For large N pass one :class:`BatchedGMMTraceGenerator` (plus ``num_envs``): all episodes of a
     boundary are drawn in one vectorised call on a worker thread while the GPU plays the current
-    episodes (~50 us per episode instead of ~2 ms through N per-environment generators).
+    episodes (~50 us per episode instead of ~2 ms through N per-environment generators).  With a
+    :class:`DeviceGMMTraceGenerator` the bank is refilled by the GPU itself (``evc_generate_episodes``,
+    ~10 ns per episode) and only the ``max_profit`` values travel to the host.
 
     ``output='numpy'`` (default) returns host arrays (SB3 / RLLib); ``'torch'`` takes and returns
     device tensors without leaving the GPU."""
@@ -330,9 +333,10 @@ class EVChargingVectorEnv:
                  output: str = 'numpy', max_sessions: int = 128):
         assert output in ('numpy', 'torch')
         self._batched = data_generators if isinstance(data_generators, BatchedGMMTraceGenerator) else None
-        if self._batched is not None:
-            assert num_envs is not None, 'num_envs is required with a BatchedGMMTraceGenerator'
-            gens = [self._batched] * num_envs
+        self._devgen = data_generators if isinstance(data_generators, DeviceGMMTraceGenerator) else None
+        if self._batched is not None or self._devgen is not None:
+            assert num_envs is not None, 'num_envs is required with a batched / device generator'
+            gens = [data_generators] * num_envs
         elif callable(data_generators):
             assert num_envs is not None
             gens = [data_generators(i) for i in range(num_envs)]
@@ -365,12 +369,16 @@ class EVChargingVectorEnv:
         moer = np.stack([g0.moer_loader.retrieve(self._day0 + timedelta(days=d)) for d in range(self._ndays)])
         self._engine.upload_moer(moer, 0)
         self._engine.set_autoreset_stride(N)
+        if self._devgen is not None:
+            self._engine.upload_gmm(self._devgen.tables)
         self._slices = obs_slices(n, k)
         self._max_profit = np.zeros(2 * N)            # per bank slot
         self._cur_slot = np.arange(N)                 # slot each env is playing
         self._episodes = np.zeros(N, dtype=np.int64)
         self._steps_in_episode = 0                    # all environments run in lock-step (288 steps)
         self._pending = None                          # (future, slots): background refill, batched mode
+        self._info_max_profit = None                  # cached per episode
+        self._false_dev = None
         self._pool = None
         self.closed = False
 
@@ -399,6 +407,20 @@ class EVChargingVectorEnv:
         else:
             self._finish_batched(slots, work())
 
+    def _stage_device(self, slots: np.ndarray) -> None:
+        """Fills ``slots`` on the GPU (one launch per contiguous run); only the max_profit values of
+        the new episodes come back to the host."""
+        g = self._devgen
+        s_sorted = np.sort(slots)
+        start = 0
+        for end in range(1, len(s_sorted) + 1):
+            if end == len(s_sorted) or s_sorted[end] != s_sorted[end - 1] + 1:
+                first, cnt = int(s_sorted[start]), end - start
+                self._engine.generate_episodes(first, cnt, g.seed, g.next_episode)
+                g.next_episode += cnt
+                self._max_profit[first:first + cnt] = self._engine.download_episodes(first, cnt, tables=False)[4]
+                start = end
+
     def _finish_batched(self, slots, drawn) -> None:
         ns, sess, req, day, mp = drawn
         self._max_profit[slots] = mp
@@ -415,6 +437,9 @@ class EVChargingVectorEnv:
         cnt = len(env_ids)
         if self._batched is not None:
             self._stage_batched(np.asarray(slots))
+            return
+        if self._devgen is not None:
+            self._stage_device(np.asarray(slots))
             return
         ns = np.zeros(cnt, np.int32)
         sess = np.zeros((cnt, self._stride), dtype=SESSION_DTYPE)
@@ -444,12 +469,14 @@ class EVChargingVectorEnv:
             seeds = list(seed)
         ids = np.arange(N)
         self._drain(force=True)
-        if self._batched is not None and seed is not None:
-            self._batched.set_seed(int(seed) if np.isscalar(seed) else int(seeds[0]))
+        if seed is not None and (self._batched is not None or self._devgen is not None):
+            gens_seed = int(seed) if np.isscalar(seed) else int(seeds[0])
+            (self._batched or self._devgen).set_seed(gens_seed)
         self._steps_in_episode = 0
         self._stage(ids, ids, seeds)                  # current episodes -> slots [0, N)
         self._stage(ids, ids + N, [None] * N)         # next episodes   -> slots [N, 2N)
         self._cur_slot = ids.copy()
+        self._info_max_profit = None
         host = self.output == 'numpy'
         obs = self._engine.reset(slots=ids, host=host)
         if host:
@@ -457,11 +484,14 @@ class EVChargingVectorEnv:
         return self._wrap_obs(obs), self._infos(None, None)
 
     def _infos(self, out, done_mask):
+        """``info['max_profit']`` is one cached array per episode (treat as read-only)."""
         bd = None if out is None else out['breakdown']
-        info = {'max_profit': self._max_profit[self._cur_slot].copy()}
+        if self._info_max_profit is None:
+            self._info_max_profit = self._max_profit[self._cur_slot]
+        info = {'max_profit': self._info_max_profit}
         if bd is not None:
             info['reward_breakdown'] = {'profit': bd[:, 0], 'carbon_cost': bd[:, 1], 'excess_charge': bd[:, 2]}
-        if done_mask is not None and done_mask.any():
+        if done_mask is not None:
             info['final_observation'] = self._wrap_obs(out['final_obs'])
             info['_final_observation'] = done_mask
             info['final_info'] = {'max_profit': self._final_max_profit}
@@ -471,29 +501,39 @@ class EVChargingVectorEnv:
     def step(self, actions):
         N = self.num_envs
         bins = self.discrete_bins if self.discrete_bins > 0 else 0
+        # All environments are reset together and every episode lasts 288 steps, so the boundary
+        # is known on the host: no device->host read of `terminated` on the torch path.
         self._steps_in_episode += 1
-        self._drain(force=self._steps_in_episode >= 288)      # next episodes must be in the bank now
+        boundary = self._steps_in_episode >= 288
+        self._drain(force=boundary)                           # next episodes must be in the bank now
         if self.output == 'numpy':
             out = self._engine.step(np.ascontiguousarray(actions), bins=bins)
             term = out['terminated'].astype(bool)
-            out = {k: (v.copy() if k in ('obs', 'reward', 'breakdown') or (k == 'final_obs' and term.any()) else v)
+            assert bool(term.all()) == boundary == bool(term.any())
+            out = {k: (v.copy() if k in ('obs', 'reward', 'breakdown') or (k == 'final_obs' and boundary) else v)
                    for k, v in out.items()}
+            truncated = np.zeros(N, dtype=bool)
         else:
             out = self._engine.step(actions, bins=bins)
             term = out['terminated'].bool()
-        done_mask = term.cpu().numpy() if hasattr(term, 'cpu') else term
-        self._final_max_profit = self._max_profit[self._cur_slot].copy()
-        if done_mask.any():
-            ids = np.nonzero(done_mask)[0]
-            vacated = self._cur_slot[ids].copy()
-            self._cur_slot[ids] = (vacated + N) % (2 * N)     # kernel autoreset: slot + stride
-            self._episodes[ids] += 1
+            truncated = self._false_dev
+            if truncated is None:
+                truncated = self._false_dev = term.new_zeros(N)
+        done_mask = None
+        if boundary:
+            done_mask = np.ones(N, dtype=bool)
+            self._final_max_profit = self._max_profit[self._cur_slot]
+            vacated = self._cur_slot.copy()
+            self._cur_slot = (vacated + N) % (2 * N)          # kernel autoreset: slot + stride
+            self._info_max_profit = None
+            self._episodes += 1
             self._steps_in_episode = 0
-            if self._batched is not None:
+            if self._devgen is not None:
+                self._stage_device(vacated)                    # one kernel launch, no host sampling
+            elif self._batched is not None:
                 self._stage_batched(vacated, background=True)  # overlaps the next episode's steps
             else:
-                self._stage(ids, vacated, [None] * len(ids))  # refill the vacated slots
-        truncated = np.zeros(N, dtype=bool) if self.output == 'numpy' else term.new_zeros(N)
+                self._stage(np.arange(N), vacated, [None] * N)  # refill the vacated slots
         return self._wrap_obs(out['obs']), out['reward'], term, truncated, self._infos(out, done_mask)
 
     def close(self) -> None:

@@ -504,3 +504,30 @@ def gmm_device_tables(site: str, date_period, requested_energy_cap: float = 100)
         'station_usage': usage.astype(np.uint32), 'num_days': g.num_days_in_date_range,
         'requested_energy_cap': float(requested_energy_cap),
     }
+
+
+class DeviceGMMTraceGenerator:
+    """Handle for on-device episode generation (``evc_generate_episodes``): names the site, the
+    date period and the seed of the counter-based random stream; holds the model tables and the
+    MOER loader.  No sampling happens on the host — pass it to ``EVChargingVectorEnv`` (with
+    ``num_envs``), which fills its episode bank on the GPU at every reset / autoreset boundary.
+    Episodes follow ``GMMsTraceGenerator``'s distribution (same GMM, rejection rules, surplus cut,
+    availability-weighted EVSE choice); episode ``e`` of seed ``s`` is reproducible bit for bit."""
+
+    def __init__(self, site: str, date_period, requested_energy_cap: float = 100, seed: int | None = None):
+        g = GMMsTraceGenerator(site, date_period, requested_energy_cap=requested_energy_cap)
+        self.site = site
+        self.date_range_str = g.date_range_str
+        self.date_range = g.date_range
+        self.num_days_in_date_range = g.num_days_in_date_range
+        self.requested_energy_cap = requested_energy_cap
+        self.moer_loader = g.moer_loader
+        self.num_stations = g.num_stations
+        self.tables = gmm_device_tables(site, date_period, requested_energy_cap)
+        self.set_seed(seed)
+
+    def set_seed(self, seed: int | None) -> None:
+        if seed is None:
+            seed = int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).view(np.uint64)[0])
+        self.seed = int(seed) & (2 ** 64 - 1)
+        self.next_episode = 0
