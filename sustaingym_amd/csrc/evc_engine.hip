@@ -257,12 +257,16 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     const int words = (e->P.G + 1) / 2;
     const bool dbg = out->pilots || out->rates || out->projected || out->returns ||
                      action_kind == EVC_ACTION_GREEDY;
+#ifndef EVC_ABL_NO_SOLVER
+#define EVC_ABL_NO_SOLVER 0   /* ablation builds only (tools/build_variant.sh): timing without the slow kernel */
+#endif
 #define EVC_LAUNCH_QUAD(W)                                                                         \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \
             if (dbg) hipLaunchKernelGGL((step_kernel_quad<true, W, true>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
             else hipLaunchKernelGGL((step_kernel_quad<true, W, false>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
             if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
+            if (!EVC_ABL_NO_SOLVER)                                                                \
             hipLaunchKernelGGL((solver_step_kernel<W>), dim3(e->solver_grid), dim3(64), 0,         \
                                e->stream, e->P, io);                                               \
         } else {                                                                                   \

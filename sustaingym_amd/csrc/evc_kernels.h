@@ -368,7 +368,10 @@ struct EnvWalker {
     __device__ __forceinline__ EnvWalker(int N, int waves_per_block) {
         const int nblk = gridDim.x;
         const int wave = rfl((int)(threadIdx.x >> 6));
-        if (nblk % 8 == 0) {
+#ifndef EVC_WALK_INTERLEAVED
+#define EVC_WALK_INTERLEAVED 0
+#endif
+        if (!EVC_WALK_INTERLEAVED && nblk % 8 == 0) {
             const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = nblk >> 3;
             const int lo = (int)(((long long)N * xcd) >> 3);
             hi = (int)(((long long)N * (xcd + 1)) >> 3);
