@@ -42,6 +42,16 @@ constexpr int kWave = 64;
 constexpr int kEmptyDep = -1;          // departure value of an empty EVSE
 constexpr int kNoArrival = 0x7fff;     // next_arrival when the session list is exhausted
 
+// compact layout: entry word = departure (10 bits, 0..288) | station (6 bits) | est_departure (16 bits)
+constexpr int kCountShift = 16;        // status word: flags in bits 0..15, entry count in bits 16..22
+constexpr int kStatusMask = 0xffff;
+__host__ __device__ __forceinline__ unsigned pack_entry(int dep, int station, int est) {
+    return ((unsigned)dep & 0x3ffu) | ((unsigned)station << 10) | ((unsigned)est << 16);
+}
+__host__ __device__ __forceinline__ int entry_dep(unsigned w) { return (int)(w & 0x3ffu); }
+__host__ __device__ __forceinline__ int entry_station(unsigned w) { return (int)((w >> 10) & 63u); }
+__host__ __device__ __forceinline__ int entry_est(unsigned w) { return (int)w >> 16; }
+
 // Per-environment scalars: two int4 per environment.
 struct EnvScalars {
     int t, cursor, slot, moer_day;                     // int4 #0
@@ -76,6 +86,11 @@ struct Params {
     int N, n, m, G, k, F;
     int bank_slots, max_sessions, moer_days;
     int autoreset, autoreset_stride, project;
+    // State layout.  compact = 0: rem / depest rows are indexed by station.  compact = 1: they hold
+    // the A plugged-in EVs of the environment as entries 0..A-1 in arbitrary order (kernels touch
+    // only those: traffic and work scale with the EVs present, not with the stations), depest packs
+    // pack_entry(), and A sits in bits 16..22 of the status word.
+    int compact;
     unsigned long long group_mask[EVC_MAX_GROUPS];  // lanes of each station class
     unsigned long long cc_mask;                     // lanes with a ClipperCreek EVSE
     // "simple" rows load a single station class (e.g. the Caltech pod breakers): they cap that

@@ -43,6 +43,8 @@ hipError_t dmalloc(T** p, size_t count) {
 
 }  // namespace
 
+constexpr bool kDefaultCompact = false;
+
 struct evc_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -86,6 +88,7 @@ struct evc_engine {
     int step_parity = 0;
     int num_cus = 256;
     int step_grid = 0, solver_grid = 0, quad_grid = 0;
+    bool compact = false;        // state layout (Params::compact)
     bool use_quad = false;
 };
 
@@ -221,7 +224,7 @@ void compute_grids(evc_engine* e) {
     const bool fits32 = (double)e->P.N * e->P.F * 4.0 < 2.0e9 && (double)e->P.N * e->P.n * 8.0 < 2.0e9 &&
                         (double)e->P.bank_slots * e->P.max_sessions * 8.0 < 2.0e9 &&
                         (double)e->P.moer_days * EVC_MOER_ROWS * EVC_MOER_COLS * 4.0 < 2.0e9;
-    e->use_quad = e->P.m <= 16 && fits32 && !(kk && strcmp(kk, "wave") == 0);
+    e->use_quad = e->P.m <= 16 && fits32 && !(kk && strcmp(kk, "wave") == 0) && !e->compact;
 }
 
 int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bins,
@@ -378,6 +381,11 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     P.autoreset = (flags & EVC_FLAG_AUTORESET) ? 1 : 0;
     P.autoreset_stride = 1;
     P.project = (flags & EVC_FLAG_PROJECT_ACTION) ? 1 : 0;
+    {
+        const char* lay = getenv("EVC_LAYOUT");          // "dense" | "compact" 
+        e->compact = lay ? strcmp(lay, "compact") == 0 : kDefaultCompact;
+        P.compact = e->compact ? 1 : 0;
+    }
     NetTables T;
     int rc = build_tables(net, P, T);
     if (rc != EVC_OK) { delete e; return rc; }
@@ -735,6 +743,7 @@ int evc_get_env_scalars(evc_engine* e, int32_t* out_host) {
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(out_host, e->d_scal, sizeof(int4) * 2 * (size_t)e->P.N, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->P.N; i++) out_host[(size_t)i * 8 + 6] &= kStatusMask;   // hide the entry count
     return EVC_OK;
 }
 
@@ -742,22 +751,50 @@ int evc_set_env_scalars(evc_engine* e, const int32_t* in_host) {
     if (!e || !in_host) return fail(EVC_EINVAL, "null argument");
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(e->d_scal, in_host, sizeof(int4) * 2 * (size_t)e->P.N, hipMemcpyHostToDevice));
+    std::vector<int> sc((size_t)e->P.N * 8);
+    HIP_TRY(hipMemcpy(sc.data(), e->d_scal, sizeof(int4) * 2 * (size_t)e->P.N, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->P.N; i++) {               // the entry count (compact layout) belongs to the station state
+        const int count_bits = sc[(size_t)i * 8 + 6] & ~kStatusMask;
+        memcpy(&sc[(size_t)i * 8], &in_host[(size_t)i * 8], sizeof(int) * 8);
+        sc[(size_t)i * 8 + 6] = (in_host[(size_t)i * 8 + 6] & kStatusMask) | count_bits;
+    }
+    HIP_TRY(hipMemcpy(e->d_scal, sc.data(), sizeof(int4) * 2 * (size_t)e->P.N, hipMemcpyHostToDevice));
     return EVC_OK;
 }
 
 int evc_get_station_state(evc_engine* e, double* rem, int16_t* dep, int16_t* est) {
     if (!e) return fail(EVC_EINVAL, "null engine");
     if (int rc = bind(e)) return rc;
-    const size_t cnt = (size_t)e->P.N * e->P.n;
+    const size_t N = (size_t)e->P.N, n = (size_t)e->P.n, cnt = N * n;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (rem) HIP_TRY(hipMemcpy(rem, e->d_rem, sizeof(double) * cnt, hipMemcpyDeviceToHost));
-    if (dep || est) {
-        std::vector<int> de(cnt);
-        HIP_TRY(hipMemcpy(de.data(), e->d_depest, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+    std::vector<int> de(cnt);
+    HIP_TRY(hipMemcpy(de.data(), e->d_depest, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+    if (!e->compact) {
+        if (rem) HIP_TRY(hipMemcpy(rem, e->d_rem, sizeof(double) * cnt, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < cnt; i++) {
             if (dep) dep[i] = (int16_t)(de[i] & 0xffff);
             if (est) est[i] = (int16_t)(de[i] >> 16);
+        }
+        return EVC_OK;
+    }
+    // compact layout: scatter the entries of every environment to their stations
+    std::vector<double> rc(cnt);
+    std::vector<int> sc(N * 8);
+    HIP_TRY(hipMemcpy(rc.data(), e->d_rem, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sc.data(), e->d_scal, sizeof(int4) * 2 * N, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cnt; i++) {
+        if (rem) rem[i] = 0.0;
+        if (dep) dep[i] = (int16_t)kEmptyDep;
+        if (est) est[i] = 0;
+    }
+    for (size_t env = 0; env < N; env++) {
+        const int A = (sc[env * 8 + 6] >> kCountShift) & 0x7f;
+        for (int a = 0; a < A; a++) {
+            const unsigned w = (unsigned)de[env * n + a];
+            const size_t i = env * n + (size_t)entry_station(w);
+            if (rem) rem[i] = rc[env * n + a];
+            if (dep) dep[i] = (int16_t)entry_dep(w);
+            if (est) est[i] = (int16_t)entry_est(w);
         }
     }
     return EVC_OK;
@@ -766,12 +803,34 @@ int evc_get_station_state(evc_engine* e, double* rem, int16_t* dep, int16_t* est
 int evc_set_station_state(evc_engine* e, const double* rem, const int16_t* dep, const int16_t* est) {
     if (!e || !rem || !dep || !est) return fail(EVC_EINVAL, "null argument");
     if (int rc = bind(e)) return rc;
-    const size_t cnt = (size_t)e->P.N * e->P.n;
+    const size_t N = (size_t)e->P.N, n = (size_t)e->P.n, cnt = N * n;
     std::vector<int> de(cnt);
-    for (size_t i = 0; i < cnt; i++) de[i] = ((int)dep[i] & 0xffff) | ((int)est[i] << 16);
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(e->d_rem, rem, sizeof(double) * cnt, hipMemcpyHostToDevice));
+    if (!e->compact) {
+        for (size_t i = 0; i < cnt; i++) de[i] = ((int)dep[i] & 0xffff) | ((int)est[i] << 16);
+        HIP_TRY(hipMemcpy(e->d_rem, rem, sizeof(double) * cnt, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->d_depest, de.data(), sizeof(int) * cnt, hipMemcpyHostToDevice));
+        return EVC_OK;
+    }
+    std::vector<double> rc(cnt, 0.0);
+    std::vector<int> sc(N * 8);
+    HIP_TRY(hipMemcpy(sc.data(), e->d_scal, sizeof(int4) * 2 * N, hipMemcpyDeviceToHost));
+    for (size_t env = 0; env < N; env++) {
+        int A = 0;
+        for (size_t s = 0; s < n; s++) {
+            const size_t i = env * n + s;
+            if (dep[i] == kEmptyDep) continue;
+            if (dep[i] < 0 || dep[i] > EVC_EPISODE_STEPS)
+                return fail(EVC_EINVAL, "evc_set_station_state: departure %d outside [0,288]", (int)dep[i]);
+            rc[env * n + A] = rem[i];
+            de[env * n + A] = (int)pack_entry(dep[i], (int)s, est[i]);
+            A++;
+        }
+        sc[env * 8 + 6] = (sc[env * 8 + 6] & kStatusMask) | (A << kCountShift);
+    }
+    HIP_TRY(hipMemcpy(e->d_rem, rc.data(), sizeof(double) * cnt, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_depest, de.data(), sizeof(int) * cnt, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_scal, sc.data(), sizeof(int4) * 2 * N, hipMemcpyHostToDevice));
     return EVC_OK;
 }
 

@@ -90,8 +90,30 @@ __device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& i
     const unsigned n = (unsigned)P.n, ul = (unsigned)lane;
     L.s0 = P.scal[2 * env];
     L.s1 = P.scal[2 * env + 1];
-    L.rem = buf_ld_f64(row_rsrc(P.rem + (size_t)env * n, n * 8u), ul * 8u);
-    L.de = (int)buf_ld_u32(row_rsrc(P.depest + (size_t)env * n, n * 4u), ul * 4u);
+    if (P.compact) {
+        // entries -> stations: every entry announces its lane at its station's cell, then each
+        // station lane pulls the entry's words with a lane gather (ds_bpermute)
+        __shared__ int entry_of[4][kWave];
+        int* cell = entry_of[threadIdx.x >> 6];
+        const unsigned A = (unsigned)(rfl(L.s1.z) >> kCountShift) & 0x7fu;
+        const double rem_e = buf_ld_f64(row_rsrc(P.rem + (size_t)env * n, A * 8u), ul * 8u);
+        const unsigned w_e = buf_ld_u32(row_rsrc(P.depest + (size_t)env * n, A * 4u), ul * 4u);
+        cell[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (ul < A) cell[entry_station(w_e)] = lane + 1;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int src = cell[lane] - 1;
+        const int from = src < 0 ? 0 : src;
+        const unsigned w_d = (unsigned)__shfl((int)w_e, from);
+        const double rem_d = __shfl(rem_e, from);
+        L.rem = src < 0 ? 0.0 : rem_d;
+        L.de = src < 0 ? (kEmptyDep & 0xffff) : (int)((w_d & 0x3ffu) | (w_d & 0xffff0000u));
+    } else {
+        L.rem = buf_ld_f64(row_rsrc(P.rem + (size_t)env * n, n * 8u), ul * 8u);
+        L.de = (int)buf_ld_u32(row_rsrc(P.depest + (size_t)env * n, n * 4u), ul * 4u);
+    }
     L.a = (io.actions && io.action_kind == EVC_ACTION_F32) ? buf_ld_f32(row_rsrc((const float*)io.actions + (size_t)env * n, n * 4u), ul * 4u) : 0.0f;
     L.acc = buf_ld_f64(row_rsrc(P.acc + (size_t)env * 3, 24u), ul * 8u);
     if (ul >= n) L.de = kEmptyDep & 0xffff;          // lanes outside the network: empty EVSE
@@ -100,7 +122,7 @@ __device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& i
 
 __device__ __forceinline__ void unpack_env(const EnvLoads& L, EnvRegs& r) {
     r.t = rfl(L.s0.x); r.cursor = rfl(L.s0.y); r.slot = rfl(L.s0.z); r.moer_day = rfl(L.s0.w);
-    r.n_sessions = rfl(L.s1.x); r.next_arrival = rfl(L.s1.y); r.status = rfl(L.s1.z); r.episodes = rfl(L.s1.w);
+    r.n_sessions = rfl(L.s1.x); r.next_arrival = rfl(L.s1.y); r.status = rfl(L.s1.z) & kStatusMask; r.episodes = rfl(L.s1.w);
     r.rem = L.rem;
     r.dep = (int)(short)(L.de & 0xffff);
     r.est = L.de >> 16;
@@ -127,13 +149,23 @@ __device__ __forceinline__ void load_env(const Params& P, int env, int lane, Env
 
 __device__ __forceinline__ void store_env(const Params& P, int env, int lane, const EnvRegs& r) {
     const unsigned n = (unsigned)P.n, ul = (unsigned)lane;
-    buf_st_f64(row_rsrc(P.rem + (size_t)env * n, n * 8u), ul * 8u, r.rem);
-    buf_st_u32(row_rsrc(P.depest + (size_t)env * n, n * 4u), ul * 4u,
-               (unsigned)((r.dep & 0xffff) | (r.est << 16)));
+    int status = r.status & kStatusMask;
+    if (P.compact) {
+        const bool occ = ul < n && r.dep != kEmptyDep;
+        const unsigned long long mask = __ballot(occ);
+        const unsigned pos = occ ? (unsigned)__popcll(mask & ((1ull << lane) - 1ull)) : 0x1fffffffu;
+        buf_st_f64(row_rsrc(P.rem + (size_t)env * n, n * 8u), pos * 8u, r.rem);
+        buf_st_u32(row_rsrc(P.depest + (size_t)env * n, n * 4u), pos * 4u, pack_entry(r.dep, lane, r.est));
+        status |= __popcll(mask) << kCountShift;
+    } else {
+        buf_st_f64(row_rsrc(P.rem + (size_t)env * n, n * 8u), ul * 8u, r.rem);
+        buf_st_u32(row_rsrc(P.depest + (size_t)env * n, n * 4u), ul * 4u,
+                   (unsigned)((r.dep & 0xffff) | (r.est << 16)));
+    }
     // the two int4 of scalars: only lane 0 is inside the 16-byte windows
     const rsrc_t s = row_rsrc(P.scal + 2 * (size_t)env, 32u);
     buf_st_i4(s, ul * 32u, make_int4(r.t, r.cursor, r.slot, r.moer_day));
-    buf_st_i4(s, ul * 32u + 16u, make_int4(r.n_sessions, r.next_arrival, r.status, r.episodes));
+    buf_st_i4(s, ul * 32u + 16u, make_int4(r.n_sessions, r.next_arrival, status, r.episodes));
 }
 
 // Puts environment registers into the state right after EVChargingEnv.reset (env.py:319-333)
@@ -433,7 +465,7 @@ __global__ __launch_bounds__(256, EVC_MIN_WAVES) void step_kernel(Params P, Step
 #endif
         if (r.t >= EVC_EPISODE_STEPS) {            // step() after termination without autoreset
             if (lane == 0) {
-                P.scal[2 * env + 1].z = r.status | EVC_STATUS_STEP_AFTER_DONE;
+                P.scal[2 * env + 1].z = cur.s1.z | EVC_STATUS_STEP_AFTER_DONE;   // keeps the entry count
                 io.out.reward[env] = 0.0;
                 io.out.terminated[env] = 1;
             }
@@ -501,7 +533,7 @@ __global__ __launch_bounds__(256) void reset_kernel(Params P, const int* env_ids
     const int slot = slots ? rfl(slots[w]) : (env % P.bank_slots);
     EnvRegs r;
     const int4 s1 = P.scal[2 * env + 1];
-    r.status = rfl(s1.z); r.episodes = rfl(s1.w);
+    r.status = rfl(s1.z) & kStatusMask; r.episodes = rfl(s1.w);
     reset_regs(P, slot, r);
     buf_st_f64(row_rsrc(P.acc + (size_t)env * 3, 24u), lane * 8u, 0.0);
     if (obs) write_obs(P, obs + (size_t)env * P.F, lane, r, moer_obs_value(P, lane, r.moer_day, 0));
@@ -543,7 +575,7 @@ __global__ __launch_bounds__(256) void metrics_kernel(Params P, double* out) {
         s1 += P.acc[(size_t)e * 3 + 1];
         s2 += P.acc[(size_t)e * 3 + 2];
         const int4 s = P.scal[2 * e + 1];
-        bad += (s.z != 0) ? 1.0 : 0.0;
+        bad += ((s.z & kStatusMask) != 0) ? 1.0 : 0.0;
         eps += (double)s.w;
     }
     s0 = wave_sum_f64(s0); s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
