@@ -1,0 +1,505 @@
+// evc_cquad.h — the streaming step kernel on the COMPACT state layout (Params::compact = 1).
+//
+// Same wavefront geometry as evc_quad.h (4 DPP rows of 16 lanes, row r = environment 4*quad + r) but
+// the per-station arithmetic — action clip, demand cap, pilot rounding, battery charge, class sums —
+// runs over the environment's ENTRIES (the EVs plugged in right now), not over its 54-64 stations:
+// lane q of a row owns entries q, q+16, q+32, q+48 ("entry slots" c = 0..3).  A Caltech / JPL day has
+// <= 16 EVs plugged in at almost every step, so normally only entry slot 0 is live and slots 1-3 are
+// skipped by one wave-uniform branch; state traffic shrinks from 2 x 12 n bytes to 12 x 16 bytes read
+// plus 12 A written.  What stays station-shaped is the interface: the action row is read densely (range
+// check) and exchanged to the entries through LDS; demands / est_departures of the observation are
+// scattered by the entries into a per-row LDS image and written out densely.
+//   * unplug = an entry with departure <= t+1 is simply not written back; survivors are packed by a
+//     ballot prefix count; a plug-in event appends one entry (written straight to memory and to the
+//     observation image by lane 0 of the row).  Entries never move between lanes.
+//   * the projection screen, the in-row water-filling and the slow queue are those of evc_quad.h,
+//     fed with the entries' class ids.
+#pragma once
+
+#include <type_traits>
+
+#include "evc_quad.h"
+
+namespace evc {
+
+struct alignas(16) StationCell {
+    float demand, est_rel;
+    double amps;
+};
+
+template <bool PROJECT, int WORDS, bool DBG>
+__global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_cquad(Params P, StepIO io) {
+    __shared__ LdsNet net;
+    __shared__ uint4 st_mulw[64];          // per station: 0 / 1 / 65536 multipliers of packed words 0..3
+    __shared__ uint4 st_mulw_hi[64];       // words 4..7
+    __shared__ unsigned char st_info[64];  // class id | ClipperCreek << 7
+    // [wave][row][station] image the entries scatter into and the station lanes read back: observation
+    // fields + delivered amps (summed in station order: the result does not depend on the entry order,
+    // i.e. not on the history of plug-ins, and equals the station-layout kernels' bit for bit); zero
+    // between steps
+    __shared__ StationCell obs_img[4][4][64];
+    __shared__ float act_img[4][4][64];    // [wave][row][station] clamped action of this step
+    __shared__ double dbg_img[DBG ? 4 : 1][4][64];
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u, q = lane & 15u, row = lane >> 4, wv = tid >> 6;
+    const unsigned n = (unsigned)P.n, F = (unsigned)P.F;
+    const unsigned m = (unsigned)P.m, k = (unsigned)P.k;
+    const unsigned N = (unsigned)P.N;
+
+    if (tid < 64u) {
+        const unsigned s = tid;
+        const bool valid = s < n;
+        int gid = 0;
+        for (int g = 0; g < P.G; g++)
+            if ((P.group_mask[g] >> s) & 1ull) gid = g;
+        unsigned mw[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) mw[w] = (valid && (gid >> 1) == w) ? ((gid & 1) ? 65536u : 1u) : 0u;
+        st_mulw[s] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+        st_mulw_hi[s] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
+        st_info[s] = (unsigned char)((unsigned)gid | ((unsigned)((P.cc_mask >> s) & 1ull) << 7));
+    }
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        obs_img[wv][row][j * 16 + q] = StationCell{0.0f, 0.0f, 0.0};
+        act_img[wv][row][j * 16 + q] = 0.0f;
+        if (DBG) dbg_img[wv][row][j * 16 + q] = 0.0;
+    }
+    stage_net(net, P);                              // ends with the workgroup barrier
+
+    StationCell* const obs_row = obs_img[wv][row];
+    float* const act_row = act_img[wv][row];
+    double* const dbg_row = dbg_img[DBG ? wv : 0][row];
+
+    // dense side: station j*16+q of the row (action range check, observation stores)
+    bool st_valid[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) st_valid[j] = (unsigned)j * 16u + q < n;
+
+    const rsrc_t r_rem = row_rsrc(P.rem, N * n * 8u);
+    const rsrc_t r_de = row_rsrc(P.depest, N * n * 4u);
+    const rsrc_t r_act = row_rsrc(io.actions, (!DBG || io.actions) ? N * n * 4u : 0u);
+    const rsrc_t r_scal = row_rsrc(P.scal, N * 32u);
+    const rsrc_t r_acc = row_rsrc(P.acc, N * 24u);
+    const rsrc_t r_obs = row_rsrc(io.out.obs, N * F * 4u);
+    const rsrc_t r_moer = row_rsrc(P.moer_obs, (unsigned)P.moer_days * EVC_MOER_ROWS * EVC_MOER_COLS * 4u);
+    const rsrc_t r_hist = row_rsrc(P.moer_hist, (unsigned)P.moer_days * EVC_MOER_ROWS * 8u);
+    const rsrc_t r_ts = row_rsrc(P.tables->timestep, EVC_MOER_ROWS * 4u);
+    const rsrc_t r_rew = row_rsrc(io.out.reward, N * 8u);
+    const rsrc_t r_term = row_rsrc(io.out.terminated, N);
+    const rsrc_t r_bd = row_rsrc(io.out.breakdown, io.out.breakdown ? N * 24u : 0u);
+    const rsrc_t r_sess = row_rsrc(P.sessions, (unsigned)P.bank_slots * (unsigned)P.max_sessions * 8u);
+    const rsrc_t r_req = row_rsrc(P.requested, (unsigned)P.bank_slots * (unsigned)P.max_sessions * 8u);
+
+    auto station_mulw = [&](unsigned st, unsigned (&mw)[WORDS]) {
+        const uint4 lo = st_mulw[st];
+        const unsigned all[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+        for (int w = 0; w < WORDS && w < 4; w++) mw[w] = all[w];
+        if (WORDS > 4) {
+            const uint4 hi = st_mulw_hi[st];
+            const unsigned allh[4] = {hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int w = 4; w < WORDS; w++) mw[w] = allh[w - 4];
+        }
+    };
+    // Cross-lane LDS hand-off inside the wave.  The LDS pipeline executes a wave's ds instructions in
+    // issue order, so only the COMPILER must be kept from reordering them; a real fence would also
+    // drain every outstanding global load and store (s_waitcnt vmcnt(0)) several times per step.
+    auto lds_sync = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    const bool greedy = DBG && io.action_kind == EVC_ACTION_GREEDY;
+    const unsigned nquads = (N + 3u) >> 2;
+    EnvWalker walk((int)nquads, 4);
+    for (int quad = walk.first; quad < walk.hi; quad += walk.stride) {
+        const unsigned env = (unsigned)quad * 4u + row;
+        const bool ev = env < N;
+        const unsigned ebase = env * n;
+
+        // ---- loads: scalars, entry slot 0 (unconditionally: its extent is known only after the
+        //      scalars arrive and a dependent load would cost a second round trip), action row ----
+        const unsigned soff = ev ? env * 32u : kOob;
+        const v4u s0 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 0, 0);
+        const v4u s1 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 16, 0);
+        unsigned meta[kSlots];
+        double rem[kSlots];
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) { meta[c] = 0u; rem[c] = 0.0; }
+        meta[0] = buf_ld_u32(r_de, ev ? (ebase + q) * 4u : kOob);
+        rem[0] = buf_ld_f64(r_rem, ev ? (ebase + q) * 8u : kOob);
+        bool clamped = false;
+        float a_st[kSlots];                         // clamped action of this lane's stations
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) a_st[j] = 0.0f;
+        if (!greedy) {
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) {
+                float a = buf_ld_f32(r_act, (ev && st_valid[j]) ? (ebase + (unsigned)j * 16u + q) * 4u : kOob);
+                clamped = clamped || !(a >= 0.0f && a <= 1.0f);          // also true for NaN
+                a_st[j] = fminf(fmaxf(a, 0.0f), 1.0f);                    // NaN -> 0
+                act_row[j * 16 + q] = a_st[j];
+            }
+        }
+        // Without the projection the schedule of EMPTY stations is non-zero too and counts in the
+        // constraint excess (env.py:449-452 evaluates the schedule, not the delivered rates): the
+        // pilots' class sums are then taken on the station side.
+        const bool station_pilots = !PROJECT && !greedy;
+        const double acc_in = buf_ld_f64(r_acc, (ev && q < 3u) ? env * 24u + q * 8u : kOob);
+
+        int t = (int)s0.x, cursor = (int)s0.y, slot = (int)s0.z, moer_day = (int)s0.w;
+        int n_sessions = (int)s1.x, next_arrival = (int)s1.y, status = (int)s1.z & kStatusMask, episodes = (int)s1.w;
+        const unsigned A = ev ? ((s1.z >> kCountShift) & 0x7fu) : 0u;
+        const bool after_done = ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
+        bool live = ev && !after_done;
+        const int t1 = t + 1;
+        const bool more = __ballot(A > 16u) != 0ull;            // wave-uniform: entry slots 1..3 in use
+        // The rest of the iteration exists twice: NS = 1 (every row of the wave has <= 16 entries: the
+        // normal case, entry slot 0 only, lean registers) and NS = 4 (general).
+        auto body = [&](auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+#pragma unroll
+        for (int c = 1; c < NS; c++) {
+            const unsigned e = (unsigned)c * 16u + q;
+            meta[c] = buf_ld_u32(r_de, e < A ? (ebase + e) * 4u : kOob);
+            rem[c] = buf_ld_f64(r_rem, e < A ? (ebase + e) * 8u : kOob);
+        }
+
+        // MOER loads for t1 (row-uniform addresses)
+        const unsigned mrow = live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) : 0u;
+        const double moer_now = buf_ld_f64(r_hist, live ? mrow * 8u : kOob);
+        float mo[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const unsigned idx = (unsigned)p * 16u + q;                 // position in [forecast | prev | ts]
+            const unsigned col = idx < k ? idx + 1u : 0u;
+            mo[p] = buf_ld_f32(r_moer, (live && idx <= k) ? (mrow * EVC_MOER_COLS + col) * 4u : kOob);
+            if (idx == k + 1u) mo[p] = buf_ld_f32(r_ts, live ? (unsigned)t1 * 4u : kOob);
+        }
+
+        // ---- entries: decode, action, y (box clip of the projection), class sums ----
+        bool valid[kSlots];
+        unsigned st[kSlots];
+        int dep[kSlots], est[kSlots];
+        float act[kSlots];
+        double y[kSlots];
+        unsigned ywords[WORDS], pwords[WORDS];
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) { ywords[w] = 0u; pwords[w] = 0u; }
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) { valid[c] = false; st[c] = 0u; dep[c] = kEmptyDep; est[c] = 0; act[c] = 0.0f; y[c] = 0.0; }
+        lds_sync();                                 // action image written above
+        auto decode = [&](int c) {
+            valid[c] = (unsigned)c * 16u + q < A;
+            st[c] = (unsigned)entry_station(meta[c]);
+            dep[c] = valid[c] ? entry_dep(meta[c]) : kEmptyDep;
+            est[c] = entry_est(meta[c]);
+            rem[c] = valid[c] ? rem[c] : 0.0;
+            float a = greedy ? ((rem[c] > Consts::FULLY_CHARGED_EPS) ? 1.0f : 0.0f) : act_row[st[c]];
+            a = valid[c] ? a : 0.0f;
+            act[c] = a;
+            double yy = (double)a * Consts::ACTION_SCALE_FACTOR;        // env.py:366
+            if (PROJECT) {
+                yy = fmin(yy, quad_demand_cap(dep[c], rem[c]));
+                const unsigned qy = (unsigned)(int)ceil(yy * 8.0);           // <= 256
+                unsigned mw[WORDS];
+                station_mulw(st[c], mw);
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) ywords[w] = __umul24(qy, mw[w]) + ywords[w];
+            }
+            y[c] = yy;
+        };
+#pragma unroll
+        for (int c = 0; c < NS; c++) decode(c);
+
+        // ---- projection screen (PROJECT) ----
+        bool pilots_screened = false;
+        if (PROJECT) {
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) ywords[w] = row_allreduce_u32(ywords[w]);
+            bool maybe = false, maybe_p = false;
+            if (q < m) {
+                const float mag2 = quad_mag2_f32<WORDS>(net, q, ywords);
+                maybe = !(mag2 < net.thr_y2[q]);
+                maybe_p = !(mag2 < net.thr_yp2[q]);
+            }
+            bool undecided = live && row_any(maybe, row);
+            pilots_screened = !row_any(maybe_p, row);
+            if (__builtin_expect(__ballot(undecided) != 0ull, 0)) {
+                // Rare (wave-uniform branch): exact float64 rows; class-cap (pod breaker) violations
+                // are projected in closed form inside the row; anything else goes to the slow kernel.
+                int st_gid[kSlots];
+#pragma unroll
+                for (int c = 0; c < kSlots; c++) st_gid[c] = valid[c] ? (int)(st_info[st[c]] & 0x7fu) : -1;
+                unsigned cap_viol;
+                bool hard = quad_exact_rows(P, net, q, m, st_gid, y, undecided, cap_viol);
+                bool nonsimple = row_any(hard && !((P.simple_rows >> q) & 1u), row);
+                bool anyviol = row_any(hard, row);
+                bool fill = undecided && anyviol && !nonsimple;
+                if (__builtin_expect(__ballot(fill) != 0ull, 0)) {
+                    for (int g = 0; g < P.G; g++) {
+                        const bool do_g = fill && ((cap_viol >> g) & 1u);
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y);
+                    }
+                    unsigned cv2;
+                    const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, 1e-6), row);
+                    nonsimple = nonsimple || (fill && still);     // could not be settled here
+                    anyviol = anyviol && !(fill && !still);
+                }
+                const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel
+                if (queue_me && q == 0u) P.slow_list[atomicAdd(P.slow_count, 1)] = (int)env;
+                live = live && !queue_me;                 // queued rows write nothing here
+                pilots_screened = pilots_screened && !undecided;
+            }
+        }
+
+        // ---- pilots (env.py:366-378), battery charge, class sums of the pilots ----
+        double pilot[kSlots], amps[kSlots];
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) { pilot[c] = 0.0; amps[c] = 0.0; }
+        auto charge = [&](int c) {
+            const unsigned info = st_info[st[c]];
+            const double pl = legal_pilot(y[c], (info >> 7) != 0u);     // y = 0 on invalid entries
+            pilot[c] = pl;
+            if (!station_pilots) {
+                const unsigned qp = (unsigned)(int)pl;                   // <= 32
+                unsigned mw[WORDS];
+                station_mulw(st[c], mw);
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) pwords[w] = __umul24(qp, mw[w]) + pwords[w];
+            }
+            amps[c] = charge_ev(pl, rem[c]);                             // every entry is a plugged-in EV
+            if (live && valid[c]) obs_row[st[c]].amps = amps[c];
+        };
+#pragma unroll
+        for (int c = 0; c < NS; c++) charge(c);
+        double pilot_st[kSlots];                   // station-side pilots (station_pilots only)
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) pilot_st[j] = 0.0;
+        if (station_pilots) {
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) {
+                const unsigned s = (unsigned)j * 16u + q;
+                const unsigned info = st_info[s];
+                pilot_st[j] = st_valid[j] ? legal_pilot((double)a_st[j] * Consts::ACTION_SCALE_FACTOR, (info >> 7) != 0u) : 0.0;
+                unsigned mw[WORDS];
+                station_mulw(s, mw);
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) pwords[w] = __umul24((unsigned)(int)pilot_st[j], mw[w]) + pwords[w];
+            }
+        }
+
+        // ---- reductions inside the row ----
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) pwords[w] = row_allreduce_u32(pwords[w]);
+        double excess = 0.0;
+        {
+            bool maybe = false;
+            if (q < m && !pilots_screened) maybe = !(quad_mag2_f32<WORDS>(net, q, pwords) < net.thr_p2[q]);
+            if (__builtin_expect(__ballot(maybe && live) != 0ull, 0)) {   // rare: exact evaluation
+                double ex = 0.0;
+                if (q < m) ex = fmax(row_mag_f64<WORDS>(net, (int)q, pwords, 1.0) - net.mag[q], 0.0);
+                excess = row_allreduce_f64(ex);
+            }
+        }
+
+        // ---- acnsim event pass at iteration t1: unplug (precedence 0) before plug-in (10) ----
+        // survivors keep their relative order; pos = index of the entry in the packed list
+        bool alive[kSlots];
+        unsigned pos[kSlots];
+        unsigned count = 0u;                                             // row-uniform
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) { alive[c] = false; pos[c] = 0u; }
+        auto pack = [&](int c) {
+            alive[c] = valid[c] && dep[c] > t1;
+            const unsigned bits = (unsigned)(__ballot(alive[c]) >> (row * 16u)) & 0xffffu;
+            pos[c] = count + (unsigned)__popc(bits & ((1u << q) - 1u));
+            count += (unsigned)__popc(bits);
+        };
+#pragma unroll
+        for (int c = 0; c < NS; c++) pack(c);
+
+        if (live) t = t1;
+        unsigned long long arrived = 0ull;                               // stations plugged in this pass
+        bool pending = live && next_arrival <= t1 && cursor < n_sessions;
+        while (__ballot(pending) != 0ull) {
+            const unsigned sidx = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
+            const v2u sv = __builtin_amdgcn_raw_buffer_load_b64(r_sess, pending ? (int)(sidx * 8u) : (int)kOob, 0, 0);
+            const double rq = buf_ld_f64(r_req, pending ? sidx * 8u : kOob);
+            const int s_dep = (int)(short)(sv.x >> 16);
+            const int s_est = (int)(short)(sv.y & 0xffffu);
+            const unsigned s_st = (sv.y >> 16) & 63u;
+            bool busy = false;
+#pragma unroll
+            for (int c = 0; c < kSlots; c++) busy = busy || (pending && alive[c] && st[c] == s_st);
+            const bool row_busy = row_any(busy, row) || ((arrived >> s_st) & 1ull);
+            if (pending && row_busy) status |= EVC_STATUS_OCCUPIED;      // acnportal: StationOccupiedError
+            const bool plug = pending && !row_busy;
+            if (plug) {
+                if (q == 0u) {
+                    buf_st_u32(r_de, (ebase + count) * 4u, pack_entry(s_dep, (int)s_st, s_est));
+                    buf_st_f64(r_rem, (ebase + count) * 8u, rq);
+                    const bool active = rq > Consts::FULLY_CHARGED_EPS;
+                    obs_row[s_st].demand = active ? (float)rq : 0.0f;
+                    obs_row[s_st].est_rel = active ? (float)(s_est - t) : 0.0f;
+                }
+                count += 1u;
+                arrived |= 1ull << s_st;
+            }
+            if (pending) {
+                cursor += 1;
+                next_arrival = kNoArrival;
+            }
+            const bool more_ev = pending && cursor < n_sessions;
+            const unsigned nx = buf_ld_u32(r_sess, more_ev ? (sidx + 1u) * 8u : kOob);
+            if (more_ev) next_arrival = (int)(short)(nx & 0xffffu);
+            pending = more_ev && next_arrival <= t1;
+        }
+        if (live && row_any(clamped, row)) status |= EVC_STATUS_ACTION_CLAMPED;
+        const bool done = live && t1 >= EVC_EPISODE_STEPS;
+        if (after_done) status |= EVC_STATUS_STEP_AFTER_DONE;
+
+        if (DBG) {                                    // per-station debug / parity outputs, dense [N][n]
+            double* outs[3] = {io.out.pilots, io.out.rates, io.out.projected};
+#pragma unroll
+            for (int o = 0; o < 3; o++) {
+                if (!outs[o]) continue;
+                if (station_pilots && o != 1) {               // schedule of every station, plugged or not
+#pragma unroll
+                    for (int j = 0; j < kSlots; j++)
+                        if (live && st_valid[j])
+                            outs[o][(size_t)ebase + (unsigned)j * 16u + q] = o == 0 ? pilot_st[j] : (double)a_st[j];
+                    continue;
+                }
+#pragma unroll
+                for (int c = 0; c < kSlots; c++)
+                    if (live && valid[c])
+                        dbg_row[st[c]] = o == 0 ? pilot[c] : (o == 1 ? amps[c] : y[c] / Consts::ACTION_SCALE_FACTOR);
+                lds_sync();
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) {
+                    const double v = dbg_row[j * 16 + q];
+                    if (live && st_valid[j]) outs[o][(size_t)ebase + (unsigned)j * 16u + q] = v;
+                }
+                lds_sync();
+#pragma unroll
+                for (int c = 0; c < kSlots; c++)
+                    if (live && valid[c]) dbg_row[st[c]] = 0.0;
+                lds_sync();
+            }
+        }
+
+        // ---- observation image: demands / est_departures of the surviving entries ----
+        auto scatter_obs = [&](int c) {
+            if (live && alive[c]) {
+                const bool active = rem[c] > Consts::FULLY_CHARGED_EPS;
+                obs_row[st[c]].demand = active ? (float)rem[c] : 0.0f;
+                obs_row[st[c]].est_rel = active ? (float)(est[c] - t) : 0.0f;
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < NS; c++) scatter_obs(c);
+        lds_sync();
+        float2 d[kSlots];
+        double amps_sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const StationCell cell = obs_row[j * 16 + q];
+            obs_row[j * 16 + q] = StationCell{0.0f, 0.0f, 0.0};  // leave the image clean for the next step
+            d[j] = make_float2(cell.demand, cell.est_rel);
+            amps_sum += cell.amps;
+        }
+        const double total_rate = row_allreduce_f64(amps_sum);           // env.py:445
+
+        // ---- reward (env.py:431-464) ----
+        const double profit = Consts::PROFIT_FACTOR * total_rate;
+        const double carbon = Consts::CARBON_COST_FACTOR * total_rate * moer_now;
+        const double excess_charge = excess * Consts::VIOLATION_FACTOR;
+        const double reward = after_done ? 0.0 : profit - carbon - excess_charge;
+        const double acc = acc_in + ((q == 0u) ? profit : (q == 1u ? carbon : excess_charge));
+        const bool wr = live || after_done;           // rows that report reward / terminated
+        buf_st_f64(r_rew, (wr && q == 0u) ? env * 8u : kOob, reward);
+        if (DBG && io.out.returns && live && q == 0u) io.out.returns[env] += reward;
+        buf_st_u8(r_term, (wr && q == 0u) ? env : kOob, (done || after_done) ? 1 : 0);
+        buf_st_f64(r_bd, (live && q < 3u) ? env * 24u + q * 8u : kOob, acc);
+
+        // ---- autoreset (gymnasium VectorEnv): terminal observation, then next episode's state ----
+        const bool do_reset = done && P.autoreset;
+        if (done) episodes += 1;
+        if (__builtin_expect(__ballot(do_reset) != 0ull, 0)) {
+            if (io.out.final_obs) {
+                const rsrc_t r_fin = row_rsrc(io.out.final_obs, N * F * 4u);
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) {
+                    const unsigned o = (do_reset && st_valid[j]) ? (env * F + (unsigned)j * 16u + q) * 4u : kOob;
+                    buf_st_f32(r_fin, o, d[j].x);
+                    buf_st_f32(r_fin, o == kOob ? kOob : o + n * 4u, d[j].y);
+                }
+#pragma unroll
+                for (int p = 0; p < 3; p++) {
+                    const unsigned idx = (unsigned)p * 16u + q;
+                    buf_st_f32(r_fin, (do_reset && idx < k + 2u) ? (env * F + 2u * n + idx) * 4u : kOob, mo[p]);
+                }
+            }
+            if (do_reset) {
+                const int next = (slot + P.autoreset_stride) % P.bank_slots;
+                slot = next;
+                t = 0; cursor = 0;
+                moer_day = P.slot_moer_day[next];
+                n_sessions = P.n_sessions[next];
+                next_arrival = n_sessions > 0 ? (int)P.sessions[(size_t)next * P.max_sessions].arrival : kNoArrival;
+                count = 0u;
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) d[j] = make_float2(0.0f, 0.0f);
+            }
+            const unsigned mrow0 = (unsigned)moer_day * EVC_MOER_ROWS;
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const unsigned idx = (unsigned)p * 16u + q;
+                const unsigned col = idx < k ? idx + 1u : 0u;
+                const float v = buf_ld_f32(r_moer, (do_reset && idx <= k) ? (mrow0 * EVC_MOER_COLS + col) * 4u : kOob);
+                if (do_reset) mo[p] = (idx == k + 1u) ? 0.0f : v;
+            }
+        }
+
+        // ---- observation (env.py:381-394) + state write-back ----
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const unsigned o = (live && st_valid[j]) ? (env * F + (unsigned)j * 16u + q) * 4u : kOob;
+            buf_st_f32(r_obs, o, d[j].x);
+            buf_st_f32(r_obs, o == kOob ? kOob : o + n * 4u, d[j].y);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const unsigned idx = (unsigned)p * 16u + q;
+            buf_st_f32(r_obs, (live && idx < k + 2u) ? (env * F + 2u * n + idx) * 4u : kOob, mo[p]);
+        }
+        auto store_entry = [&](int c) {
+            const bool w = live && alive[c] && !do_reset;
+            buf_st_u32(r_de, w ? (ebase + pos[c]) * 4u : kOob, meta[c]);
+            buf_st_f64(r_rem, w ? (ebase + pos[c]) * 8u : kOob, rem[c]);
+        };
+#pragma unroll
+        for (int c = 0; c < NS; c++) store_entry(c);
+        buf_st_f64(r_acc, (live && q < 3u) ? env * 24u + q * 8u : kOob, do_reset ? 0.0 : acc);
+        {
+            v4u o0, o1;
+            o0.x = (unsigned)t; o0.y = (unsigned)cursor; o0.z = (unsigned)slot; o0.w = (unsigned)moer_day;
+            o1.x = (unsigned)n_sessions; o1.y = (unsigned)next_arrival;
+            o1.z = ((unsigned)status & (unsigned)kStatusMask) | ((live ? count : A) << kCountShift);
+            o1.w = (unsigned)episodes;
+            const unsigned so = ((live || after_done) && q == 0u) ? env * 32u : kOob;
+            __builtin_amdgcn_raw_buffer_store_b128(o0, r_scal, (int)so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o1, r_scal, (int)so, 16, 0);
+        }
+        };
+        if (__builtin_expect(more, 0)) body(std::integral_constant<int, 4>{});
+        else body(std::integral_constant<int, 1>{});
+        lds_sync();
+    }
+}
+
+}  // namespace evc

@@ -12,6 +12,7 @@
 
 #include "evc_solver.h"
 #include "evc_quad.h"
+#include "evc_cquad.h"
 #include "evc_gen.h"
 
 using namespace evc;
@@ -43,7 +44,7 @@ hipError_t dmalloc(T** p, size_t count) {
 
 }  // namespace
 
-constexpr bool kDefaultCompact = false;
+constexpr bool kDefaultCompact = true;
 
 struct evc_engine {
     int device = 0;
@@ -224,7 +225,7 @@ void compute_grids(evc_engine* e) {
     const bool fits32 = (double)e->P.N * e->P.F * 4.0 < 2.0e9 && (double)e->P.N * e->P.n * 8.0 < 2.0e9 &&
                         (double)e->P.bank_slots * e->P.max_sessions * 8.0 < 2.0e9 &&
                         (double)e->P.moer_days * EVC_MOER_ROWS * EVC_MOER_COLS * 4.0 < 2.0e9;
-    e->use_quad = e->P.m <= 16 && fits32 && !(kk && strcmp(kk, "wave") == 0) && !e->compact;
+    e->use_quad = e->P.m <= 16 && fits32 && !(kk && strcmp(kk, "wave") == 0);
 }
 
 int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bins,
@@ -263,22 +264,30 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
 #ifndef EVC_ABL_NO_SOLVER
 #define EVC_ABL_NO_SOLVER 0   /* ablation builds only (tools/build_variant.sh): timing without the slow kernel */
 #endif
-#define EVC_LAUNCH_QUAD(W)                                                                         \
+#define EVC_LAUNCH_QUAD_(KQ, W)                                                                         \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \
-            if (dbg) hipLaunchKernelGGL((step_kernel_quad<true, W, true>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
-            else hipLaunchKernelGGL((step_kernel_quad<true, W, false>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
+            if (dbg) hipLaunchKernelGGL((KQ<true, W, true>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
+            else hipLaunchKernelGGL((KQ<true, W, false>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
             if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
             if (!EVC_ABL_NO_SOLVER)                                                                \
             hipLaunchKernelGGL((solver_step_kernel<W>), dim3(e->solver_grid), dim3(64), 0,         \
                                e->stream, e->P, io);                                               \
         } else {                                                                                   \
-            if (dbg) hipLaunchKernelGGL((step_kernel_quad<false, W, true>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
-            else hipLaunchKernelGGL((step_kernel_quad<false, W, false>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
+            if (dbg) hipLaunchKernelGGL((KQ<false, W, true>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
+            else hipLaunchKernelGGL((KQ<false, W, false>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
             if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
         }                                                                                          \
         break;
-    if (e->use_quad) {
+#define EVC_LAUNCH_QUAD(W) EVC_LAUNCH_QUAD_(step_kernel_quad, W)
+#define EVC_LAUNCH_CQUAD(W) EVC_LAUNCH_QUAD_(step_kernel_cquad, W)
+    if (e->use_quad && e->compact) {
+        switch (words) {
+            EVC_LAUNCH_CQUAD(1) EVC_LAUNCH_CQUAD(2) EVC_LAUNCH_CQUAD(3) EVC_LAUNCH_CQUAD(4)
+            EVC_LAUNCH_CQUAD(5) EVC_LAUNCH_CQUAD(6) EVC_LAUNCH_CQUAD(7) EVC_LAUNCH_CQUAD(8)
+            default: return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
+        }
+    } else if (e->use_quad) {
         switch (words) {
             EVC_LAUNCH_QUAD(1) EVC_LAUNCH_QUAD(2) EVC_LAUNCH_QUAD(3) EVC_LAUNCH_QUAD(4)
             EVC_LAUNCH_QUAD(5) EVC_LAUNCH_QUAD(6) EVC_LAUNCH_QUAD(7) EVC_LAUNCH_QUAD(8)
@@ -286,6 +295,8 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         }
     } else
 #undef EVC_LAUNCH_QUAD
+#undef EVC_LAUNCH_CQUAD
+#undef EVC_LAUNCH_QUAD_
 #define EVC_LAUNCH(W)                                                                              \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \

@@ -98,11 +98,12 @@ __device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& i
         const unsigned A = (unsigned)(rfl(L.s1.z) >> kCountShift) & 0x7fu;
         const double rem_e = buf_ld_f64(row_rsrc(P.rem + (size_t)env * n, A * 8u), ul * 8u);
         const unsigned w_e = buf_ld_u32(row_rsrc(P.depest + (size_t)env * n, A * 4u), ul * 4u);
+        // (LDS executes a wave's ds instructions in issue order: compiler barriers suffice)
         cell[lane] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (ul < A) cell[entry_station(w_e)] = lane + 1;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         const int src = cell[lane] - 1;
         const int from = src < 0 ? 0 : src;
