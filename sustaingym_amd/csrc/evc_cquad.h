@@ -115,22 +115,48 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_cquad(Params 
     const bool greedy = DBG && io.action_kind == EVC_ACTION_GREEDY;
     const unsigned nquads = (N + 3u) >> 2;
     EnvWalker walk((int)nquads, 4);
+    // Raw loads of one quad, issued one iteration ahead (software prefetch): the waves of this kernel
+    // spend most of their time waiting for these round trips (SQ_WAIT_ANY = 60 % of the wave cycles).
+    struct QuadRaw {
+        v4u s0, s1;
+        unsigned meta0;
+        double rem0;
+        float a[kSlots];
+        double acc;
+    };
+    auto issue = [&](int quad_) {
+        QuadRaw L;
+        const unsigned env_ = (unsigned)quad_ * 4u + row;
+        const bool ev_ = quad_ < walk.hi && env_ < N;
+        const unsigned eb_ = env_ * n;
+        const unsigned soff = ev_ ? env_ * 32u : kOob;
+        L.s0 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 0, 0);
+        L.s1 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 16, 0);
+        // entry slot 0 unconditionally: its extent is known only after the scalars arrive, and a
+        // dependent load would cost a second round trip
+        L.meta0 = buf_ld_u32(r_de, ev_ ? (eb_ + q) * 4u : kOob);
+        L.rem0 = buf_ld_f64(r_rem, ev_ ? (eb_ + q) * 8u : kOob);
+#pragma unroll
+        for (int j = 0; j < kSlots; j++)
+            L.a[j] = greedy ? 0.0f : buf_ld_f32(r_act, (ev_ && st_valid[j]) ? (eb_ + (unsigned)j * 16u + q) * 4u : kOob);
+        L.acc = buf_ld_f64(r_acc, (ev_ && q < 3u) ? env_ * 24u + q * 8u : kOob);
+        return L;
+    };
+    QuadRaw nxt = issue(walk.first);
     for (int quad = walk.first; quad < walk.hi; quad += walk.stride) {
         const unsigned env = (unsigned)quad * 4u + row;
         const bool ev = env < N;
         const unsigned ebase = env * n;
+        const QuadRaw cur = nxt;
+        nxt = issue(quad + walk.stride);
 
-        // ---- loads: scalars, entry slot 0 (unconditionally: its extent is known only after the
-        //      scalars arrive and a dependent load would cost a second round trip), action row ----
-        const unsigned soff = ev ? env * 32u : kOob;
-        const v4u s0 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 0, 0);
-        const v4u s1 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 16, 0);
+        const v4u s0 = cur.s0, s1 = cur.s1;
         unsigned meta[kSlots];
         double rem[kSlots];
 #pragma unroll
         for (int c = 0; c < kSlots; c++) { meta[c] = 0u; rem[c] = 0.0; }
-        meta[0] = buf_ld_u32(r_de, ev ? (ebase + q) * 4u : kOob);
-        rem[0] = buf_ld_f64(r_rem, ev ? (ebase + q) * 8u : kOob);
+        meta[0] = cur.meta0;
+        rem[0] = cur.rem0;
         bool clamped = false;
         float a_st[kSlots];                         // clamped action of this lane's stations
 #pragma unroll
@@ -138,7 +164,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_cquad(Params 
         if (!greedy) {
 #pragma unroll
             for (int j = 0; j < kSlots; j++) {
-                float a = buf_ld_f32(r_act, (ev && st_valid[j]) ? (ebase + (unsigned)j * 16u + q) * 4u : kOob);
+                const float a = cur.a[j];
                 clamped = clamped || !(a >= 0.0f && a <= 1.0f);          // also true for NaN
                 a_st[j] = fminf(fmaxf(a, 0.0f), 1.0f);                    // NaN -> 0
                 act_row[j * 16 + q] = a_st[j];
@@ -148,7 +174,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_cquad(Params 
         // constraint excess (env.py:449-452 evaluates the schedule, not the delivered rates): the
         // pilots' class sums are then taken on the station side.
         const bool station_pilots = !PROJECT && !greedy;
-        const double acc_in = buf_ld_f64(r_acc, (ev && q < 3u) ? env * 24u + q * 8u : kOob);
+        const double acc_in = cur.acc;
 
         int t = (int)s0.x, cursor = (int)s0.y, slot = (int)s0.z, moer_day = (int)s0.w;
         int n_sessions = (int)s1.x, next_arrival = (int)s1.y, status = (int)s1.z & kStatusMask, episodes = (int)s1.w;
