@@ -128,6 +128,7 @@ def main():
             if project:
                 slow_cnt.append(eng.last_slow_count())
         eng.enable_timing(False)
+        layout = os.environ.get('EVC_LAYOUT', 'compact')          # engine default
         avg_main = float(np.mean(main_ms))
         avg_slow = float(np.mean(slow_ms))
         bytes_per_launch = algorithmic_bytes_per_env_step(n, k) * N
@@ -137,13 +138,14 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f'{args.site}_N{N}_project{int(project)}'
+                key = f'{args.site}_N{N}_project{int(project)}' + ('' if layout == 'dense' else f'_{layout}')
                 traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
-        roofline = {'bound': 'hbm', 'kernel': 'evc::step_kernel_quad', 'achieved': round(achieved, 2),
+        roofline = {'bound': 'hbm', 'kernel': 'evc::step_kernel_cquad' if layout == 'compact' else 'evc::step_kernel_quad',
+                    'achieved': round(achieved, 2),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
-                    'traffic': traffic, 'avg_kernel_ms': round(avg_main, 5),
+                    'traffic': traffic, 'state_layout': layout, 'avg_kernel_ms': round(avg_main, 5),
                     'solver_kernel_ms': round(avg_slow, 5),
                     'slow_queue_envs_per_step': (round(float(np.mean(slow_cnt)), 1) if slow_cnt else 0.0),
                     'algorithmic_bytes_per_launch': bytes_per_launch}

@@ -27,8 +27,12 @@ struct alignas(16) StationCell {
     double amps;
 };
 
+#ifndef EVC_CQUAD_WAVES
+#define EVC_CQUAD_WAVES 4
+#endif
+
 template <bool PROJECT, int WORDS, bool DBG>
-__global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_cquad(Params P, StepIO io) {
+__global__ __launch_bounds__(256, EVC_CQUAD_WAVES) void step_kernel_cquad(Params P, StepIO io) {
     __shared__ LdsNet net;
     __shared__ uint4 st_mulw[64];          // per station: 0 / 1 / 65536 multipliers of packed words 0..3
     __shared__ uint4 st_mulw_hi[64];       // words 4..7

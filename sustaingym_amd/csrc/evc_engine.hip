@@ -213,7 +213,7 @@ void compute_grids(evc_engine* e) {
     // register footprint admits), every wave walks several quads.  Measured best on MI355X
     // (tools/ab_caps.py): 1024 workgroups 30-32 us vs 4096 workgroups 35.6 us per step at N = 65 536.
     int qblocks = (((e->P.N + 3) / 4) + 3) / 4;          // quads per wave, 4 waves per workgroup
-    int qcap = 4 * e->num_cus;
+    int qcap = (e->compact ? EVC_CQUAD_WAVES : EVC_QUAD_WAVES) * e->num_cus;
     if (const char* s = getenv("EVC_GRID_CAP")) qcap = atoi(s) > 0 ? atoi(s) : qcap;
     if (qblocks > qcap) qblocks = qcap;
     if (qblocks >= 8) qblocks -= qblocks % 8;
