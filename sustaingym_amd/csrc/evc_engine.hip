@@ -206,7 +206,11 @@ void compute_grids(evc_engine* e) {
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks -= blocks % 8;
     e->step_grid = blocks;
-    int scap = 256;          // the slow queue is nearly always empty or tiny; queued envs are looped over
+    // Slow kernel: one 64-lane workgroup per queued environment, 24 kB of LDS each -> 6 resident per CU.
+    // On a quiet network the queue is empty (the launch costs ~2 us); on a congested one (most EVSEs
+    // occupied, feeder limits binding) a third of the environments queue up, and 256 workgroups took
+    // 737 us per step where 1536 take ~300 (tools/ab_busy.py).
+    int scap = 6 * e->num_cus;
     if (const char* s = getenv("EVC_SOLVER_GRID")) scap = atoi(s) > 0 ? atoi(s) : scap;
     e->solver_grid = e->P.N < scap ? e->P.N : scap;
     // Streaming (quad) kernel: persistent-style grid of 4 workgroups per CU (= the 4 waves/SIMD its
