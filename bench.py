@@ -43,6 +43,8 @@ def parse_args():
     p.add_argument('--no-project', action='store_true', help='project_action_in_env=False')
     p.add_argument('--bank', type=int, default=8192, help='distinct synthetic episodes resident in HBM')
     p.add_argument('--ring', type=int, default=8, help='distinct action batches resident in HBM')
+    p.add_argument('--busy', action='store_true',
+                   help='congested variant of the workload (30-60 long sessions per day); not the headline')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-envs', type=int, default=2048)
     p.add_argument('--cpu-steps', type=int, default=96)
@@ -78,7 +80,8 @@ def main():
     project = not args.no_project
     P = min(args.bank, max(N, 1))
     moer_days = 32
-    ns, sess, req, day = synthetic_episodes(P, n, seed=1000 + rank, stride=64, moer_days=moer_days)
+    busy_kw = dict(min_sessions=30, max_sessions=60, max_arrival=120, min_duration=40, max_duration=160) if args.busy else {}
+    ns, sess, req, day = synthetic_episodes(P, n, seed=1000 + rank, stride=64, moer_days=moer_days, **busy_kw)
     moer = synthetic_moer(moer_days, seed=7)
     eng = StepEngine(net, N, moer_forecast_steps=k, project_action=project, autoreset=True,
                      device=local_rank, bank_slots=P, max_sessions=64, moer_days=moer_days)
@@ -198,7 +201,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
             'config': {'workload': f'{N} batched {n}-station EVChargingEnv ({args.site}) per GPU, continuous '
-                                   f'actions, project_action_in_env={project}, autoreset over a {P}-episode bank',
+                                   f'actions, project_action_in_env={project}, autoreset over a {P}-episode bank' + (' [congested variant]' if args.busy else ''),
                        'envs_per_gpu': N, 'global_envs': N * world, 'parallelism': f'env-shard x{world}',
                        'actions': 'U[0,1) float32 resident in HBM'},
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'episode_generation': episode_generation,
