@@ -40,7 +40,7 @@ class GmmDesc(C.Structure):
 def build(force: bool = False) -> str:
     """Compiles the oracle with gcc (oracle/Makefile)."""
     srcs = [os.path.join(_HERE, f) for f in
-            ('evc_oracle.c', 'evc_oracle_proj.c', 'evc_oracle_gen.c', 'evc_oracle.h', 'evc_oracle_priv.h')]
+            ('evc_oracle.c', 'evc_oracle_proj.c', 'evc_oracle_gen.c', 'bat_oracle.c', 'evc_oracle.h', 'evc_oracle_priv.h')]
     stale = (not os.path.exists(_LIB_PATH) or
              any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs))
     if force or stale:
@@ -88,6 +88,16 @@ def lib() -> C.CDLL:
         L.orc_gen_normal.argtypes = [C.c_double]
         L.orc_generate_episode.restype = i32
         L.orc_generate_episode.argtypes = [C.POINTER(GmmDesc), i32, C.c_uint64, C.c_uint64, i32, vp, vp, vp, vp]
+        L.bor_create.restype = vp
+        L.bor_create.argtypes = [i32] + [C.c_double] * 6
+        L.bor_destroy.argtypes = [vp]
+        L.bor_reset.argtypes = [vp, vp, vp, vp, vp, vp, C.c_double, vp]
+        L.bor_step.restype = i32
+        L.bor_step.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
+        L.bor_energy.restype = C.c_double
+        L.bor_energy.argtypes = [vp]
+        L.bor_t.restype = i32
+        L.bor_t.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -289,3 +299,36 @@ class OracleGenerator:
 
 def max_threads() -> int:
     return lib().orc_max_threads()
+
+
+class OracleBattery:
+    """bat_oracle.c: one battery-dispatch environment (synthetic workload, parity unpinned)."""
+
+    def __init__(self, k=36, capacity_mwh=80.0, max_power_mw=20.0, eta_charge=0.95, eta_discharge=0.95,
+                 init_energy_mwh=40.0, co2_price_per_kg=0.03085):
+        self.k, self.F = k, 4 * k + 6
+        self.handle = lib().bor_create(k, capacity_mwh, max_power_mw, eta_charge, eta_discharge, init_energy_mwh,
+                                       co2_price_per_kg)
+        self._obs = np.zeros(self.F, np.float32)
+        self._keep = None
+
+    def __del__(self):
+        if getattr(self, 'handle', None) and _lib is not None:
+            _lib.bor_destroy(self.handle)
+            self.handle = None
+
+    def reset(self, price, load, load_fc, moer, moer_fc, terminal_price):
+        self._keep = [np.ascontiguousarray(a, dtype=np.float32) for a in (price, load, load_fc, moer, moer_fc)]
+        k = self._keep
+        lib().bor_reset(self.handle, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), float(terminal_price), _p(self._obs))
+        return self._obs.copy()
+
+    def step(self, bids):
+        b = np.ascontiguousarray(bids, dtype=np.float32)
+        r = C.c_double()
+        done = lib().bor_step(self.handle, _p(b), _p(self._obs), C.byref(r))
+        return self._obs.copy(), r.value, bool(done)
+
+    @property
+    def energy(self):
+        return lib().bor_energy(self.handle)

@@ -7,6 +7,7 @@ Public surface (mirrors ``sustaingym.envs.evcharging``):
     RealTraceGenerator, GMMsTraceGenerator, BatchedGMMTraceGenerator,
     DeviceGMMTraceGenerator                                             (episode generators)
     StepEngine                                                          (C-ABI handle)
+    BatteryDispatchVectorEnv                                            (config 4, synthetic: battery.py)
 
 The HIP library is loaded lazily (``sustaingym_amd._lib.load``); importing the package does not
 need a GPU, constructing an environment does.
@@ -21,6 +22,9 @@ def __getattr__(name):
     if name == 'StepEngine':
         from .engine import StepEngine
         return StepEngine
+    if name == 'BatteryDispatchVectorEnv':
+        from .battery import BatteryDispatchVectorEnv
+        return BatteryDispatchVectorEnv
     if name in ('EVChargingEnv', 'MultiAgentEVChargingEnv', 'DiscreteActionWrapper',
                 'EVChargingVectorEnv', 'SB3VecEnv', 'MultiAgentEVChargingVectorEnv'):
         from . import envs

@@ -94,6 +94,29 @@ SIGNATURES = {
     'evc_last_step_ms': (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 
+class BatConfig(C.Structure):
+    _fields_ = [('num_envs', C.c_int32), ('forecast_steps', C.c_int32), ('bank_slots', C.c_int32),
+                ('device', C.c_int32), ('capacity_mwh', C.c_double), ('max_power_mw', C.c_double),
+                ('eta_charge', C.c_double), ('eta_discharge', C.c_double), ('init_energy_mwh', C.c_double),
+                ('co2_price_per_kg', C.c_double)]
+
+
+# Every symbol include/battery_dispatch.h declares
+BAT_SIGNATURES = {
+    'bat_create': (_i32, [C.POINTER(BatConfig), C.POINTER(_vp)]),
+    'bat_destroy': (None, [_vp]),
+    'bat_last_error': (C.c_char_p, []),
+    'bat_obs_dim': (_i32, [_vp]),
+    'bat_set_stream': (_i32, [_vp, _vp]),
+    'bat_upload_traces': (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bat_reset': (_i32, [_vp, _vp, _vp]),
+    'bat_step': (_i32, [_vp, _vp, _vp, _vp, _vp]),
+    'bat_reset_host': (_i32, [_vp, _vp, _vp]),
+    'bat_step_host': (_i32, [_vp, _vp, _vp, _vp, _vp]),
+    'bat_get_state': (_i32, [_vp, _vp, _vp]),
+    'bat_read_metrics': (_i32, [_vp, _vp]),
+}
+
 _lib = None
 
 
@@ -117,7 +140,7 @@ def load() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:  # e.g. libamdhip64 missing
         raise EngineLibraryError(f'cannot load {LIB_PATH}: {exc}') from exc
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(BAT_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as exc:

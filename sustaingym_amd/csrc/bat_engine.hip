@@ -1,0 +1,272 @@
+// bat_engine.hip — gfx950 implementation of include/battery_dispatch.h (a synthetic workload: see the
+// header).  One wavefront per environment: the few scalars of the step are computed wave-uniformly,
+// the 4k+6-float observation row is written lane-parallel.  HBM-bound on the observation write
+// (600 B per env-step at k = 36) plus the 2k-float bid read.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/battery_dispatch.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(x)                                                                       \
+    do {                                                                                 \
+        hipError_t err_ = (x);                                                           \
+        if (err_ != hipSuccess) return fail(-4, "%s: %s", #x, hipGetErrorString(err_)); \
+    } while (0)
+
+struct BatParams {
+    int N, k, F, bank_slots;
+    double cap, step_mwh, eta_c, eta_d, e0, pco2;
+    double* energy;          // [N]
+    double* ret;             // [N] sum of rewards since reset
+    int* t;                  // [N]
+    int* slot;               // [N]
+    const float* price;      // [slots][289]
+    const float* load;
+    const float* moer;
+    const float* load_fc;    // [slots][289 + k]
+    const float* moer_fc;
+    const double* terminal_price;   // [slots]
+};
+
+__device__ __forceinline__ void write_obs(const BatParams& P, float* row, int lane, int t, double e, int slot,
+                                          const float* bids, float x, float p, float l, float m) {
+    const int k = P.k;
+    // [t, e, a(2k), x, p, l, lhat(k), m, mhat(k)]
+    for (int i = lane; i < P.F; i += 64) {
+        float v;
+        if (i == 0) v = (float)t;
+        else if (i == 1) v = (float)e;
+        else if (i < 2 + 2 * k) v = bids ? bids[i - 2] : 0.0f;
+        else if (i == 2 + 2 * k) v = x;
+        else if (i == 3 + 2 * k) v = p;
+        else if (i == 4 + 2 * k) v = l;
+        else if (i < 5 + 3 * k) v = P.load_fc[(size_t)slot * (BAT_TRACE_LEN + k) + t + 1 + (i - (5 + 2 * k))];
+        else if (i == 5 + 3 * k) v = m;
+        else v = P.moer_fc[(size_t)slot * (BAT_TRACE_LEN + k) + t + 1 + (i - (6 + 3 * k))];
+        row[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bat_reset_kernel(BatParams P, const int* slots, float* obs) {
+    const int lane = threadIdx.x & 63;
+    const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (env >= P.N) return;
+    const int slot = slots ? slots[env] : env % P.bank_slots;
+    if (lane == 0) { P.energy[env] = P.e0; P.ret[env] = 0.0; P.t[env] = 0; P.slot[env] = slot; }
+    // first observation: nothing has happened yet (previous action / dispatch / price / load / MOER = 0)
+    write_obs(P, obs + (size_t)env * P.F, lane, 0, P.e0, slot, nullptr, 0.0f, 0.0f, 0.0f, 0.0f);
+    // forecasts in the first observation start at index 1 like every later one (lhat[t+1 .. t+k])
+}
+
+__global__ __launch_bounds__(256) void bat_step_kernel(BatParams P, const float* bids, float* obs, double* reward,
+                                                       unsigned char* terminated) {
+    const int lane = threadIdx.x & 63;
+    const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (env >= P.N) return;
+    const int t = P.t[env];
+    if (t >= BAT_EPISODE_STEPS) {                       // step after termination: no-op, reward 0
+        if (lane == 0) { reward[env] = 0.0; terminated[env] = 1; }
+        return;
+    }
+    const int slot = P.slot[env];
+    const double e = P.energy[env];
+    const float* a = bids + (size_t)env * 2 * P.k;
+    const double bid_c = (double)a[0], bid_d = (double)a[P.k];
+    const size_t tr = (size_t)slot * BAT_TRACE_LEN + t;
+    const float pf = P.price[tr], lf = P.load[tr], mf = P.moer[tr];
+    const double p = (double)pf, m = (double)mf;
+    const bool sell = p >= bid_d, buy = p <= bid_c;
+    double x = 0.0, e1 = e;
+    if (sell && !buy) {
+        x = fmin(P.step_mwh, P.eta_d * e);
+        e1 = e - x / P.eta_d;
+    } else if (buy && !sell) {
+        x = -fmin(P.step_mwh, (P.cap - e) / P.eta_c);
+        e1 = e - P.eta_c * x;
+    }
+    e1 = fmin(fmax(e1, 0.0), P.cap);
+    const int t1 = t + 1;
+    const bool done = t1 >= BAT_EPISODE_STEPS;
+    double r = p * x + P.pco2 * m * x;
+    if (done) r -= P.terminal_price[slot] * fmax(0.0, P.e0 - e1);
+    write_obs(P, obs + (size_t)env * P.F, lane, t1, e1, slot, a, (float)x, pf, lf, mf);
+    if (lane == 0) {
+        P.energy[env] = e1;
+        P.t[env] = t1;
+        P.ret[env] += r;
+        reward[env] = r;
+        terminated[env] = done ? 1 : 0;
+    }
+}
+
+__global__ void bat_metrics_kernel(BatParams P, double* out) {
+    double se = 0.0, sr = 0.0, done = 0.0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < P.N; e += gridDim.x * blockDim.x) {
+        se += P.energy[e]; sr += P.ret[e]; done += P.t[e] >= BAT_EPISODE_STEPS ? 1.0 : 0.0;
+    }
+    atomicAdd(&out[0], se); atomicAdd(&out[1], sr); atomicAdd(&out[3], done);
+}
+
+}  // namespace
+
+struct bat_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    BatParams P{};
+    bat_config cfg{};
+    unsigned long long env_steps = 0;
+    int* d_slots = nullptr;
+    float* d_bids = nullptr;
+    float* d_obs = nullptr;
+    double* d_reward = nullptr;
+    unsigned char* d_term = nullptr;
+    double* d_metrics = nullptr;
+    std::vector<void*> owned;
+};
+
+extern "C" {
+
+const char* bat_last_error(void) { return g_err; }
+
+int bat_create(const bat_config* cfg, bat_engine** out) {
+    if (!cfg || !out) return fail(-1, "bat_create: null argument");
+    if (cfg->num_envs < 1 || cfg->forecast_steps < 1 || cfg->forecast_steps > BAT_MAX_FORECAST || cfg->bank_slots < 1)
+        return fail(-1, "bat_create: bad num_envs / forecast_steps / bank_slots");
+    if (!(cfg->capacity_mwh > 0) || !(cfg->max_power_mw > 0) || !(cfg->eta_charge > 0 && cfg->eta_charge <= 1) ||
+        !(cfg->eta_discharge > 0 && cfg->eta_discharge <= 1) || !(cfg->init_energy_mwh >= 0 && cfg->init_energy_mwh <= cfg->capacity_mwh))
+        return fail(-1, "bat_create: bad battery parameters");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= cfg->device)
+        return fail(-2, "bat_create: no HIP device %d (there is no CPU path)", cfg->device);
+    HIP_TRY(hipSetDevice(cfg->device));
+    bat_engine* e = new bat_engine();
+    e->device = cfg->device;
+    e->cfg = *cfg;
+    BatParams& P = e->P;
+    P.N = cfg->num_envs; P.k = cfg->forecast_steps; P.F = 4 * P.k + 6; P.bank_slots = cfg->bank_slots;
+    P.cap = cfg->capacity_mwh; P.step_mwh = cfg->max_power_mw * (5.0 / 60.0);
+    P.eta_c = cfg->eta_charge; P.eta_d = cfg->eta_discharge; P.e0 = cfg->init_energy_mwh; P.pco2 = cfg->co2_price_per_kg;
+    const size_t N = P.N, S = P.bank_slots, k = P.k;
+    auto alloc = [&](void** p, size_t bytes) -> hipError_t {
+        hipError_t r = hipMalloc(p, bytes);
+        if (r == hipSuccess) { e->owned.push_back(*p); r = hipMemset(*p, 0, bytes); }
+        return r;
+    };
+#define BA(ptr, bytes) do { if (alloc((void**)&(ptr), (bytes)) != hipSuccess) { bat_destroy(e); return fail(-3, "bat_create: hipMalloc failed"); } } while (0)
+    BA(P.energy, N * 8); BA(P.ret, N * 8); BA(P.t, N * 4); BA(P.slot, N * 4);
+    BA(P.price, S * BAT_TRACE_LEN * 4); BA(P.load, S * BAT_TRACE_LEN * 4); BA(P.moer, S * BAT_TRACE_LEN * 4);
+    BA(P.load_fc, S * (BAT_TRACE_LEN + k) * 4); BA(P.moer_fc, S * (BAT_TRACE_LEN + k) * 4); BA(P.terminal_price, S * 8);
+    BA(e->d_slots, N * 4); BA(e->d_bids, N * 2 * k * 4); BA(e->d_obs, N * (4 * k + 6) * 4); BA(e->d_reward, N * 8);
+    BA(e->d_term, N); BA(e->d_metrics, 4 * 8);
+#undef BA
+    *out = e;
+    return 0;
+}
+
+void bat_destroy(bat_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->owned) (void)hipFree(p);
+    delete e;
+}
+
+int bat_obs_dim(const bat_engine* e) { return e ? e->P.F : -1; }
+int bat_set_stream(bat_engine* e, void* s) { if (!e) return fail(-1, "null engine"); e->stream = (hipStream_t)s; return 0; }
+
+int bat_upload_traces(bat_engine* e, int32_t first, int32_t count, const float* price, const float* load,
+                      const float* load_fc, const float* moer, const float* moer_fc, const double* terminal_price) {
+    if (!e || !price || !load || !load_fc || !moer || !moer_fc || !terminal_price) return fail(-1, "bat_upload_traces: null argument");
+    if (first < 0 || count < 1 || first + count > e->P.bank_slots) return fail(-1, "bat_upload_traces: slots outside the bank");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const size_t T = BAT_TRACE_LEN, Tk = BAT_TRACE_LEN + e->P.k, c = count, f = first;
+    HIP_TRY(hipMemcpy((void*)(e->P.price + f * T), price, c * T * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((void*)(e->P.load + f * T), load, c * T * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((void*)(e->P.moer + f * T), moer, c * T * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((void*)(e->P.load_fc + f * Tk), load_fc, c * Tk * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((void*)(e->P.moer_fc + f * Tk), moer_fc, c * Tk * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((void*)(e->P.terminal_price + f), terminal_price, c * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int bat_reset(bat_engine* e, const int32_t* slots, float* obs_dev) {
+    if (!e || !obs_dev) return fail(-1, "bat_reset: null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const int* dslots = nullptr;
+    if (slots) {
+        for (int i = 0; i < e->P.N; i++)
+            if (slots[i] < 0 || slots[i] >= e->P.bank_slots) return fail(-1, "bat_reset: slot %d outside the bank", slots[i]);
+        HIP_TRY(hipMemcpyAsync(e->d_slots, slots, sizeof(int) * e->P.N, hipMemcpyHostToDevice, e->stream));
+        dslots = e->d_slots;
+    }
+    hipLaunchKernelGGL(bat_reset_kernel, dim3((e->P.N + 3) / 4), dim3(256), 0, e->stream, e->P, dslots, obs_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int bat_step(bat_engine* e, const float* bids_dev, float* obs_dev, double* reward_dev, uint8_t* terminated_dev) {
+    if (!e || !bids_dev || !obs_dev || !reward_dev || !terminated_dev) return fail(-1, "bat_step: null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(bat_step_kernel, dim3((e->P.N + 3) / 4), dim3(256), 0, e->stream, e->P, bids_dev, obs_dev,
+                       reward_dev, terminated_dev);
+    HIP_TRY(hipGetLastError());
+    e->env_steps += (unsigned long long)e->P.N;
+    return 0;
+}
+
+int bat_reset_host(bat_engine* e, const int32_t* slots, float* obs_host) {
+    if (!e || !obs_host) return fail(-1, "bat_reset_host: null argument");
+    if (int rc = bat_reset(e, slots, e->d_obs)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(obs_host, e->d_obs, sizeof(float) * (size_t)e->P.N * e->P.F, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bat_step_host(bat_engine* e, const float* bids_host, float* obs_host, double* reward_host, uint8_t* terminated_host) {
+    if (!e || !bids_host || !obs_host || !reward_host || !terminated_host) return fail(-1, "bat_step_host: null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(e->d_bids, bids_host, sizeof(float) * (size_t)e->P.N * 2 * e->P.k, hipMemcpyHostToDevice, e->stream));
+    if (int rc = bat_step(e, e->d_bids, e->d_obs, e->d_reward, e->d_term)) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(obs_host, e->d_obs, sizeof(float) * (size_t)e->P.N * e->P.F, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(reward_host, e->d_reward, sizeof(double) * e->P.N, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(terminated_host, e->d_term, e->P.N, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bat_get_state(bat_engine* e, double* energy_host, int32_t* t_host) {
+    if (!e) return fail(-1, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (energy_host) HIP_TRY(hipMemcpy(energy_host, e->P.energy, sizeof(double) * e->P.N, hipMemcpyDeviceToHost));
+    if (t_host) HIP_TRY(hipMemcpy(t_host, e->P.t, sizeof(int) * e->P.N, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bat_read_metrics(bat_engine* e, double* out_host) {
+    if (!e || !out_host) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(e->d_metrics, 0, 4 * sizeof(double), e->stream));
+    hipLaunchKernelGGL(bat_metrics_kernel, dim3(64), dim3(256), 0, e->stream, e->P, e->d_metrics);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(out_host, e->d_metrics, 4 * sizeof(double), hipMemcpyDeviceToHost));
+    out_host[2] = (double)e->env_steps;
+    return 0;
+}
+
+}  // extern "C"

@@ -32,7 +32,7 @@ struct alignas(16) StationCell {
 #endif
 
 template <bool PROJECT, int WORDS, bool DBG>
-__global__ __launch_bounds__(256, EVC_CQUAD_WAVES) void step_kernel_cquad(Params P, StepIO io) {
+__global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cquad(Params P, StepIO io) {
     __shared__ LdsNet net;
     __shared__ uint4 st_mulw[64];          // per station: 0 / 1 / 65536 multipliers of packed words 0..3
     __shared__ uint4 st_mulw_hi[64];       // words 4..7

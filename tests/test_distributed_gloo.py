@@ -70,3 +70,58 @@ def test_two_gloo_ranks_match_single_process():
     # identity without a process group
     pr, tot = all_gather_metrics(expect)
     assert np.array_equal(tot, expect) and pr.shape == (1, 6)
+
+
+# ---- BASELINE config 4: battery-dispatch environments sharded over the ranks ---------------------
+
+def _battery_shard_returns(lo, hi, steps=40):
+    """Sum of rewards / final energies of global environments [lo, hi): traces and bids are functions of
+    the GLOBAL environment id, so a shard's result does not depend on how the job is partitioned.  The
+    CPU ranks of this test step the oracle (test infrastructure); GPU ranks run
+    sustaingym_amd.battery.BatteryDispatchVectorEnv on the same inputs."""
+    from oracle.binding import OracleBattery
+    from sustaingym_amd.battery import synthetic_market_traces
+    k = 4
+    out = np.zeros(len(METRIC_NAMES))
+    for env_id in range(lo, hi):
+        tr = synthetic_market_traces(1, k, seed=500 + env_id)
+        o = OracleBattery(k)
+        o.reset(tr['price'][0], tr['load'][0], tr['load_fc'][0], tr['moer'][0], tr['moer_fc'][0], tr['terminal_price'][0])
+        rng = np.random.default_rng(env_id)
+        ret = 0.0
+        for _ in range(steps):
+            _, r, _ = o.step(rng.uniform(0, 90, 2 * k).astype(np.float32))
+            ret += r
+        out += np.array([ret, o.energy, 0.0, steps, 0.0, 0.0])
+    return out
+
+
+def _battery_worker(rank, world, port, global_envs, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lo, hi = shard_range(global_envs, rank, world)
+    per_rank, total = all_gather_metrics(_battery_shard_returns(lo, hi))
+    dist.barrier()
+    if rank == 0:
+        q.put((per_rank, total))
+    dist.destroy_process_group()
+
+
+def test_battery_envs_shard_over_two_gloo_ranks():
+    global_envs, world = 9, 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_battery_worker, args=(r, world, port, global_envs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    per_rank, total = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = _battery_shard_returns(0, global_envs)
+    np.testing.assert_allclose(total, expect, rtol=1e-12)
+    assert total[3] == 40 * global_envs and per_rank.shape == (2, len(METRIC_NAMES))
