@@ -3,4 +3,4 @@
 set -e
 mkdir -p sustaingym_amd/variants
 cd sustaingym_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I../../include -Wno-unused-function $2 -shared -o ../variants/lib_$1.so evc_engine.hip 2>&1 | grep -i "error" || true
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I../../include -Wno-unused-function $2 -shared -o ../variants/lib_$1.so evc_engine.hip bat_engine.hip 2>&1 | grep -i "error" || true
