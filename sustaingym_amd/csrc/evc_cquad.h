@@ -187,8 +187,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         bool live = ev && !after_done;
         const int t1 = t + 1;
         const bool more = __ballot(A > 16u) != 0ull;            // wave-uniform: entry slots 1..3 in use
-        // The rest of the iteration exists twice: NS = 1 (every row of the wave has <= 16 entries: the
-        // normal case, entry slot 0 only, lean registers) and NS = 4 (general).
+        // The rest of the iteration is instantiated for NS = 1..4 entry slots per lane: the widest row of
+        // the wave decides (NS = 1: every row has <= 16 entries, the normal case of a quiet network;
+        // midday on a real Caltech / JPL day needs 2-3).  Registers — and spills, all of them in the
+        // NS >= 2 copies — grow with NS, so a single general copy would make every busy hour pay for
+        // 64 entries: 99-121 us per step at Caltech's midday with NS in {1,4}, 54-64 us with {1,2,3,4}.
         auto body = [&](auto ns_tag) {
         constexpr int NS = decltype(ns_tag)::value;
 #pragma unroll
@@ -526,8 +529,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             __builtin_amdgcn_raw_buffer_store_b128(o1, r_scal, (int)so, 16, 0);
         }
         };
-        if (__builtin_expect(more, 0)) body(std::integral_constant<int, 4>{});
-        else body(std::integral_constant<int, 1>{});
+        if (__builtin_expect(more, 0)) {
+            if (__ballot(A > 48u) != 0ull) body(std::integral_constant<int, 4>{});
+            else if (__ballot(A > 32u) != 0ull) body(std::integral_constant<int, 3>{});
+            else body(std::integral_constant<int, 2>{});
+        } else {
+            body(std::integral_constant<int, 1>{});
+        }
         lds_sync();
     }
 }

@@ -899,6 +899,16 @@ int evc_last_slow_count(evc_engine* e, int32_t* count) {
     return EVC_OK;
 }
 
+#ifdef EVC_SOLVER_STATS
+int evc_debug_solver_stats(unsigned long long* out8) {
+    static const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(evc::g_solver_stats), sizeof(zero)) != hipSuccess) return -4;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(evc::g_solver_stats), zero, sizeof(zero)) != hipSuccess) return -4;
+    return 0;
+}
+#endif
+
 int evc_enable_timing(evc_engine* e, int32_t on) {
     if (!e) return fail(EVC_EINVAL, "null engine");
     e->timing = on != 0;

@@ -106,12 +106,20 @@ __device__ __forceinline__ bool quad_exact_rows(const Params& P, const LdsNet& n
 
 // Water-filling of class g inside each row flagged `on` (see waterfill_class in evc_kernels.h):
 // nu >= 0 with sum_{class g} clip(b - nu, 0, h) = cap; safeguarded Newton, row-local reductions.
-// b and h are recomputed from live registers (act, dep, rem) instead of being kept in arrays, and
-// y is updated in place, so this rare path adds no register pressure to the streaming kernel.
+// y is updated in place.
 __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gid)[kSlots],
                                                const float (&act)[kSlots], const int (&dep)[kSlots],
                                                const double (&rem)[kSlots], double cap,
                                                double (&y)[kSlots]) {
+    // target b and cap h of every slot, once (slots that are compile-time empty fold away)
+    double b[kSlots], h[kSlots];
+    bool in_g[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        in_g[j] = st_gid[j] == g;
+        b[j] = (double)act[j] * Consts::ACTION_SCALE_FACTOR;
+        h[j] = quad_demand_cap(dep[j], rem[j]);
+    }
     double nu = 0.0, lo = 0.0, hi = 64.0;
     bool run = on;
     for (int it = 0; it < 80 && __ballot(run) != 0ull; it++) {
@@ -119,13 +127,10 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
         unsigned nfree = 0u;
 #pragma unroll
         for (int j = 0; j < kSlots; j++) {
-            const bool in_g = st_gid[j] == g;
-            const double b = (double)act[j] * Consts::ACTION_SCALE_FACTOR;
-            const double h = quad_demand_cap(dep[j], rem[j]);
-            const double v = b - nu;
-            part += in_g ? fmin(fmax(v, 0.0), h) : 0.0;
-            nfree += (in_g && v > 0.0 && v <= h && h > 0.0) ? 1u : 0u;
-            nextbp = fmin(nextbp, (in_g && v > h) ? b - h : 1e300);
+            const double v = b[j] - nu;
+            part += in_g[j] ? fmin(fmax(v, 0.0), h[j]) : 0.0;
+            nfree += (in_g[j] && v > 0.0 && v <= h[j] && h[j] > 0.0) ? 1u : 0u;
+            nextbp = fmin(nextbp, (in_g[j] && v > h[j]) ? b[j] - h[j] : 1e300);
         }
         const double f = row_allreduce_f64(part) - cap;
         const unsigned kfree = row_allreduce_u32(nfree);
@@ -143,12 +148,10 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
     }
 #pragma unroll
     for (int j = 0; j < kSlots; j++) {
-        if (on && st_gid[j] == g) {
-            const double b = (double)act[j] * Consts::ACTION_SCALE_FACTOR;
-            const double h = quad_demand_cap(dep[j], rem[j]);
-            const double yw = fmin(fmax(b - nu, 0.0), h);
+        if (on && in_g[j]) {
+            const double yw = fmin(fmax(b[j] - nu, 0.0), h[j]);
             // tie snap of solver-moved values
-            y[j] = (yw != fmin(b, h)) ? tie_snap(yw, h) : yw;
+            y[j] = (yw != fmin(b[j], h[j])) ? tie_snap(yw, h[j]) : yw;
         }
     }
 }

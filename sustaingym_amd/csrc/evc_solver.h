@@ -25,6 +25,13 @@ constexpr int kMaxActive = 16;              // rows simultaneously in the Newton
 constexpr int kMaxDim = 2 * kMaxActive;
 constexpr int kSolverMaxIter = 60;
 
+#ifdef EVC_SOLVER_STATS   // diagnostic builds only (tools/build_variant.sh): work statistics of the slow kernel
+__device__ unsigned long long g_solver_stats[8];
+#define SOLVER_STAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_solver_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define SOLVER_STAT(i, v) do { } while (0)
+#endif
+
 struct SolverLds {
     LdsNet net;
     double z[EVC_MAX_CONSTRAINTS][2];       // accepted multipliers
@@ -211,20 +218,43 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
                 }
             }
         }
+        SOLVER_STAT(0, 1);
+        SOLVER_STAT(1, settled ? 1 : 0);
         if (!settled) solver_pass(P, L, ln, lane, L.z);
+        int n_iter = 0, n_trial = 0, n_act = 0;
 
         double mu = 1e-3;
         bool converged = settled, last_ok = false;
         for (int it = 0; it < kSolverMaxIter && !settled; it++) {
+            n_iter++;
             double g0, g1, nz, nw;
             row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
             const double rc = lane < m ? L.net.mag[lane] : 1.0;
             // activate violated rows that have no multiplier yet
             const bool newly = lane < m && nz == 0.0 && nw > rc * (1.0 + Consts::PROJ_TOL);
-            if (__ballot(newly) != 0ull) {
+            const unsigned long long newly_rows = __ballot(newly);
+            if (newly_rows != 0ull) {
+                // First activation (no multiplier yet anywhere): start every violated row at the
+                // first-order size of its multiplier along w — moving z_c by lam w^ lowers |w_c| by
+                // about lam w^'(M_c diag(k) M_c')w^ — divided by the number of rows activated together,
+                // whose corrections add up.  (A tiny start costs several expansion passes of the line
+                // search per row: 12-15 passes per solve instead of 5; unscaled, a fully saturated
+                // network overshoots into the flat region and cycles.)  Rows that become violated
+                // later, beside active ones, start tiny and let the Newton system place them.
+                const bool first = __ballot(lane < m && nz > 0.0) == 0ull;
                 if (newly) {
-                    L.z[lane][0] = 1e-6 * L.w[lane][0] / nw;
-                    L.z[lane][1] = 1e-6 * L.w[lane][1] / nw;
+                    const double wh0 = L.w[lane][0] / nw, wh1 = L.w[lane][1] / nw;
+                    double lam = 1e-6;
+                    if (first) {
+                        double curv = 0.0;
+                        for (int g = 0; g < G; g++) {
+                            const double pr = L.net.Mre[g][lane] * wh0 + L.net.Mim[g][lane] * wh1;
+                            curv += L.kfree[g] * pr * pr;
+                        }
+                        if (curv > 0.0) lam = fmax((nw - rc) / (curv * (double)__popcll(newly_rows)), 1e-6);
+                    }
+                    L.z[lane][0] = lam * wh0;
+                    L.z[lane][1] = lam * wh1;
                 }
                 __syncthreads();
                 solver_pass(P, L, ln, lane, L.z);
@@ -250,6 +280,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
                 active &= ~(1ull << last);
             }
             const int na = __popcll(active);
+            n_act = na;
             const int d = 2 * na;
             const bool mine = lane < m && ((active >> lane) & 1ull);
             const int jrow = __popcll(active & ((1ull << lane) - 1ull));
@@ -296,6 +327,8 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
             // line search on the sign of the directional derivative
             double alpha = 1.0;
             double dd = solver_trial(P, L, ln, lane, active, alpha);
+            n_trial++;
+            bool state_current = true;            // L.w / L.S / L.kfree / ln.y belong to the accepted point
             if (dd > 0.25 * dd0) {
                 // undershoot (flat piece): expand while the derivative stays positive
                 accept_trial(L, m, lane);         // alpha = 1 is an ascent point
@@ -304,7 +337,8 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
                 // the displacement bookkeeping simple by expanding from the accepted point.
                 while (dd > 0.25 * dd0 && best_alpha < 1e6) {
                     const double dd2 = solver_trial(P, L, ln, lane, active, 3.0 * best_alpha);
-                    if (dd2 < -0.5 * dd0) break;
+                    n_trial++;
+                    if (dd2 < -0.5 * dd0) { state_current = false; break; }     // rejected trial
                     accept_trial(L, m, lane);
                     best_alpha *= 4.0;
                     dd = dd2;
@@ -316,12 +350,17 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
                     alpha *= 0.5;
                     nback++;
                     dd = solver_trial(P, L, ln, lane, active, alpha);
+                    n_trial++;
                 }
                 accept_trial(L, m, lane);
                 mu = (nback > 1) ? mu * 4.0 : fmax(mu * 0.25, 1e-12);
             }
-            solver_pass(P, L, ln, lane, L.z);     // state of the accepted point
+            // the pass of the last trial already left the state of the accepted point, unless that
+            // trial was rejected
+            if (!state_current) solver_pass(P, L, ln, lane, L.z);
         }
+        SOLVER_STAT(2, n_iter); SOLVER_STAT(3, n_trial); SOLVER_STAT(4, n_act); SOLVER_STAT(5, n_iter >= 20 ? 1 : 0);
+        SOLVER_STAT(6, n_act == 1 ? 1 : 0); SOLVER_STAT(7, (!converged && !last_ok) ? 1 : 0);
         if (!converged && !last_ok) r.status |= EVC_STATUS_PROJ_NOCONV;
         // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
         // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.

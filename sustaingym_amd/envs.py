@@ -379,6 +379,9 @@ class EVChargingVectorEnv:
         self._pending = None                          # (future, slots): background refill, batched mode
         self._info_max_profit = None                  # cached per episode
         self._false_dev = None
+        self._stepper = None
+        self._stepper_out = None
+        self._stepper_stream = None
         self._pool = None
         self.closed = False
 
@@ -514,8 +517,19 @@ class EVChargingVectorEnv:
                    for k, v in out.items()}
             truncated = np.zeros(N, dtype=bool)
         else:
-            out = self._engine.step(actions, bins=bins)
-            term = out['terminated'].bool()
+            import torch
+            if bins == 0 and actions.dtype == torch.float32 and actions.is_contiguous() and actions.is_cuda:
+                # lean path: one ctypes call per step on a pre-built argument block
+                stream = torch.cuda.current_stream(actions.device).cuda_stream
+                if self._stepper is None or stream != self._stepper_stream:
+                    self._stepper, self._stepper_out = self._engine.make_stepper()
+                    self._stepper_stream = stream
+                assert tuple(actions.shape) == (N, self.num_stations)
+                self._stepper(actions.data_ptr())
+                out = self._stepper_out
+            else:
+                out = self._engine.step(actions, bins=bins)
+            term = out['terminated'].view(torch.bool)             # uint8 0/1: zero-copy
             truncated = self._false_dev
             if truncated is None:
                 truncated = self._false_dev = term.new_zeros(N)

@@ -84,7 +84,15 @@ class Solver:
             newly = (nz == 0) & (nw > r * (1 + tol))
             if np.any(newly):
                 z = z.copy()
-                z[newly] = 1e-6 * w[newly] / nw[newly, None]
+                if getattr(self, 'smart_start', False) and (newly.sum() == 1 or '--scaled' in sys.argv) and not np.any(nz > 0):
+                    for c in np.where(newly)[0]:
+                        wh = w[c] / nw[c]
+                        pr = self.M[c, 0] * wh[0] + self.M[c, 1] * wh[1]
+                        curv = float(np.sum(k * pr * pr))
+                        lam = (nw[c] - r[c]) / curv if curv > 0 else 1e-6
+                        z[c] = max(lam / newly.sum(), 1e-6) * wh
+                else:
+                    z[newly] = 1e-6 * w[newly] / nw[newly, None]
                 y, S, k, w = self.station_pass(z, b, h)
                 g, nz, nw = self.grad(z, w)
             A = np.where(nz > 0)[0]
@@ -149,6 +157,7 @@ def main():
     rng = np.random.default_rng(0)
     for net in (caltech_acn(), jpl_acn()):
         sol = Solver(net)
+        sol.smart_start = '--smart' in sys.argv
         print(net.site, 'G =', sol.G)
         n = net.num_stations
         worst = 0.0
