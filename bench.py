@@ -45,6 +45,9 @@ def parse_args():
     p.add_argument('--ring', type=int, default=8, help='distinct action batches resident in HBM')
     p.add_argument('--busy', action='store_true',
                    help='congested variant of the workload (30-60 long sessions per day); not the headline')
+    p.add_argument('--episodes', default='synthetic', choices=['synthetic', 'gmm'],
+                   help="'gmm': the bank is generated on the device from the reference's GMM (Summer 2019) - busier\n"
+                        'days than the synthetic default; not the headline')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-envs', type=int, default=2048)
     p.add_argument('--cpu-steps', type=int, default=96)
@@ -84,9 +87,16 @@ def main():
     ns, sess, req, day = synthetic_episodes(P, n, seed=1000 + rank, stride=64, moer_days=moer_days, **busy_kw)
     moer = synthetic_moer(moer_days, seed=7)
     eng = StepEngine(net, N, moer_forecast_steps=k, project_action=project, autoreset=True,
-                     device=local_rank, bank_slots=P, max_sessions=64, moer_days=moer_days)
+                     device=local_rank, bank_slots=P, max_sessions=128 if args.episodes == 'gmm' else 64,
+                     moer_days=moer_days)
     eng.upload_moer(moer)
-    eng.upload_episodes(ns, sess, req, day)
+    if args.episodes == 'gmm':
+        from sustaingym_amd.event_generation import gmm_device_tables
+        eng.upload_gmm(dict(gmm_device_tables(args.site, 'Summer 2019'), num_days=moer_days))
+        eng.generate_episodes(0, P, 1000 + rank, 0)
+        ns, sess, req, day, _ = eng.download_episodes(0, P)          # for the cpu_baseline leg
+    else:
+        eng.upload_episodes(ns, sess, req, day)
     eng.set_autoreset_stride(1)
     eng.reset()
     gen = torch.Generator(device=dev)
@@ -199,9 +209,9 @@ def main():
             'value': round(value, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 5),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-            'data': 'synthetic',
+            'data': 'synthetic' if args.episodes == 'synthetic' else 'synthetic actions / MOER, episodes sampled on the device from the packaged GMM',
             'config': {'workload': f'{N} batched {n}-station EVChargingEnv ({args.site}) per GPU, continuous '
-                                   f'actions, project_action_in_env={project}, autoreset over a {P}-episode bank' + (' [congested variant]' if args.busy else ''),
+                                   f'actions, project_action_in_env={project}, autoreset over a {P}-episode bank' + (' [congested variant]' if args.busy else '') + (' [GMM episodes]' if args.episodes == 'gmm' else ''),
                        'envs_per_gpu': N, 'global_envs': N * world, 'parallelism': f'env-shard x{world}',
                        'actions': 'U[0,1) float32 resident in HBM'},
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'episode_generation': episode_generation,
