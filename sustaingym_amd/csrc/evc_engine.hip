@@ -900,8 +900,8 @@ int evc_last_slow_count(evc_engine* e, int32_t* count) {
 }
 
 #ifdef EVC_SOLVER_STATS
-int evc_debug_solver_stats(unsigned long long* out8) {
-    static const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int evc_debug_solver_stats(unsigned long long* out8 /* [16] */) {
+    static const unsigned long long zero[16] = {0};
     if (hipDeviceSynchronize() != hipSuccess) return -4;
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(evc::g_solver_stats), sizeof(zero)) != hipSuccess) return -4;
     if (hipMemcpyToSymbol(HIP_SYMBOL(evc::g_solver_stats), zero, sizeof(zero)) != hipSuccess) return -4;

@@ -26,11 +26,17 @@ constexpr int kMaxDim = 2 * kMaxActive;
 constexpr int kSolverMaxIter = 60;
 
 #ifdef EVC_SOLVER_STATS   // diagnostic builds only (tools/build_variant.sh): work statistics of the slow kernel
-__device__ unsigned long long g_solver_stats[8];
+__device__ unsigned long long g_solver_stats[16];
+#define SOLVER_CLK() clock64()
 #define SOLVER_STAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_solver_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define SOLVER_STAT(i, v) do { } while (0)
+#define SOLVER_CLK() 0ll
 #endif
+
+// One workgroup = one wavefront: LDS hand-offs between lanes need no s_barrier (the LDS pipeline
+// executes a wave's ds instructions in issue order), only a compiler barrier.
+#define SOLVER_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 struct SolverLds {
     LdsNet net;
@@ -42,6 +48,8 @@ struct SolverLds {
     double kfree[EVC_MAX_GROUPS];
     double H[kMaxDim][kMaxDim + 1];
     double dir[kMaxDim];
+    double zn[EVC_MAX_CONSTRAINTS];         // |z_c| and z_c / |z_c| of the active rows
+    double zh[EVC_MAX_CONSTRAINTS][2];
     int act[kMaxActive];
 };
 
@@ -61,7 +69,7 @@ __device__ __forceinline__ void solver_pass(const Params& P, SolverLds& L, Solve
             nu += L.net.Mre[lane][c] * zsrc[c][0] + L.net.Mim[lane][c] * zsrc[c][1];
         L.nu[lane] = nu;
     }
-    __syncthreads();
+    SOLVER_SYNC();
     double v = 0.0;
     bool is_free = false;
     ln.y = 0.0;
@@ -78,7 +86,7 @@ __device__ __forceinline__ void solver_pass(const Params& P, SolverLds& L, Solve
             L.kfree[g] = (double)__popcll(free_mask & P.group_mask[g]);
         }
     }
-    __syncthreads();
+    SOLVER_SYNC();
     if (lane < m) {
         double re = 0.0, im = 0.0;
         for (int g = 0; g < G; g++) {
@@ -88,7 +96,7 @@ __device__ __forceinline__ void solver_pass(const Params& P, SolverLds& L, Solve
         L.w[lane][0] = re;
         L.w[lane][1] = im;
     }
-    __syncthreads();
+    SOLVER_SYNC();
 }
 
 // gradient of q for row c = lane at multipliers zsrc (0 for inactive rows)
@@ -124,7 +132,7 @@ __device__ __forceinline__ double solver_trial(const Params& P, SolverLds& L, So
         L.zt[lane][0] = t0;
         L.zt[lane][1] = t1;
     }
-    __syncthreads();
+    SOLVER_SYNC();
     solver_pass(P, L, ln, lane, L.zt);
     double g0, g1, nz, nw;
     row_gradient(L, m, lane, L.zt, g0, g1, nz, nw);
@@ -136,7 +144,7 @@ __device__ __forceinline__ double solver_trial(const Params& P, SolverLds& L, So
 
 __device__ __forceinline__ void accept_trial(SolverLds& L, int m, int lane) {
     if (lane < m) { L.z[lane][0] = L.zt[lane][0]; L.z[lane][1] = L.zt[lane][1]; }
-    __syncthreads();
+    SOLVER_SYNC();
 }
 
 // In-LDS Cholesky solve of the d x d system (lane a owns row a and rhs a); result in L.dir.
@@ -150,10 +158,10 @@ __device__ __forceinline__ void solver_cholesky(SolverLds& L, int d, int lane, d
         double piv = readlane_f64(t, j);
         piv = piv < 1e-300 ? 1e-300 : piv;
         const double ljj = sqrt(piv);
-        __syncthreads();
+        SOLVER_SYNC();
         if (lane == j) L.H[j][j] = ljj;
         else if (lane > j && lane < d) L.H[lane][j] = t / ljj;
-        __syncthreads();
+        SOLVER_SYNC();
     }
     // forward substitution L u = rhs
     for (int i = 0; i < d; i++) {
@@ -168,7 +176,47 @@ __device__ __forceinline__ void solver_cholesky(SolverLds& L, int d, int lane, d
         else if (lane < i) rhs -= L.H[i][lane] * xi;
     }
     if (lane < d) L.dir[lane] = rhs;
-    __syncthreads();
+    SOLVER_SYNC();
+}
+
+// D x D system (D = 2, 4) solved redundantly by every lane in registers (Gauss elimination without
+// pivoting: H is SPD plus the Levenberg-Marquardt shift): no LDS round trips, readlanes or barriers
+// between the steps, which is what the in-LDS Cholesky spends its time on at these sizes.
+template <int D>
+__device__ __forceinline__ void solver_small(SolverLds& L, int lane, double rhs) {
+    double A[D][D], x[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        x[i] = readlane_f64(rhs, i);
+#pragma unroll
+        for (int j = 0; j < D; j++) A[i][j] = L.H[i][j];
+    }
+    double inv[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        double piv = A[k][k];
+        piv = piv < 1e-300 ? 1e-300 : piv;
+        inv[k] = 1.0 / piv;
+#pragma unroll
+        for (int i = k + 1; i < D; i++) {
+            const double f = A[i][k] * inv[k];
+#pragma unroll
+            for (int j = k + 1; j < D; j++) A[i][j] -= f * A[k][j];
+            x[i] -= f * x[k];
+        }
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; i--) {
+        double acc = x[i];
+#pragma unroll
+        for (int j = i + 1; j < D; j++) acc -= A[i][j] * x[j];
+        x[i] = acc * inv[i];
+    }
+    double mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; i++) mine = lane == i ? x[i] : mine;
+    if (lane < D) L.dir[lane] = mine;
+    SOLVER_SYNC();
 }
 
 template <int WORDS>
@@ -185,6 +233,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
     ln.gid = lnet.gid;
 
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        long long c0 = SOLVER_CLK();
         const int env = rfl(P.slow_list[q]);
         const EnvLoads cur = issue_loads(P, io, env, lane);
         EnvRegs r;
@@ -194,7 +243,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
         ln.b = a * Consts::ACTION_SCALE_FACTOR;
         ln.h = demand_cap_amps(r);
         if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; }
-        __syncthreads();
+        SOLVER_SYNC();
 
         // (a) the screen of the streaming kernel may have been merely inconclusive: exact test of
         //     the box clip; (b) only class caps (pod breakers) violated: closed-form water-filling
@@ -218,6 +267,9 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
                 }
             }
         }
+        long long c1 = SOLVER_CLK();
+        SOLVER_STAT(8, c1 - c0);
+        long long t_build = 0, t_chol = 0, t_ls = 0, t_head = 0;
         SOLVER_STAT(0, 1);
         SOLVER_STAT(1, settled ? 1 : 0);
         if (!settled) solver_pass(P, L, ln, lane, L.z);
@@ -227,6 +279,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
         bool converged = settled, last_ok = false;
         for (int it = 0; it < kSolverMaxIter && !settled; it++) {
             n_iter++;
+            long long ca = SOLVER_CLK();
             double g0, g1, nz, nw;
             row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
             const double rc = lane < m ? L.net.mag[lane] : 1.0;
@@ -256,7 +309,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
                     L.z[lane][0] = lam * wh0;
                     L.z[lane][1] = lam * wh1;
                 }
-                __syncthreads();
+                SOLVER_SYNC();
                 solver_pass(P, L, ln, lane, L.z);
                 row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
             }
@@ -281,49 +334,54 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
             }
             const int na = __popcll(active);
             n_act = na;
+            long long cb = SOLVER_CLK(); t_head += cb - ca;
             const int d = 2 * na;
             const bool mine = lane < m && ((active >> lane) & 1ull);
             const int jrow = __popcll(active & ((1ull << lane) - 1ull));
             if (mine) L.act[jrow] = lane;
-            __syncthreads();
-            // build H (lane a owns row a = 2*j + p  <->  row act[j], component p)
+            SOLVER_SYNC();
+            // Newton system, one ELEMENT per lane (d*d <= 1024 elements, row a = 2*j + p <-> active row
+            // act[j], component p): H_ab = sum_g M_a[g] k_g M_b[g]  (+ the curvature of r_c ||z_c|| on the
+            // 2x2 diagonal blocks); rhs = gradient of the active rows.
+            if (mine) {
+                const double z0 = L.z[lane][0], z1 = L.z[lane][1];
+                const double nzc = sqrt(z0 * z0 + z1 * z1);
+                L.zn[lane] = nzc; L.zh[lane][0] = z0 / nzc; L.zh[lane][1] = z1 / nzc;
+            }
+            SOLVER_SYNC();
+            for (int e = lane; e < d * d; e += kWave) {
+                const int a = e / d, bcol = e - a * d;
+                const int ja = a >> 1, pa = a & 1, ca = L.act[ja];
+                const int jb = bcol >> 1, pb = bcol & 1, cb = L.act[jb];
+                double hsum = 0.0;
+                for (int g = 0; g < G; g++) {
+                    const double ma = pa ? L.net.Mim[g][ca] : L.net.Mre[g][ca];
+                    const double mb = pb ? L.net.Mim[g][cb] : L.net.Mre[g][cb];
+                    hsum += ma * L.kfree[g] * mb;
+                }
+                if (jb == ja)
+                    hsum += (L.net.mag[ca] / L.zn[ca]) * ((pa == pb ? 1.0 : 0.0) - L.zh[ca][pa] * L.zh[ca][pb]);
+                L.H[a][bcol] = hsum;
+            }
             double rhs = 0.0;
             if (lane < d) {
-                const int ja = lane >> 1, pa = lane & 1, ca = L.act[ja];
-                double diag = 0.0;
-                for (int bcol = 0; bcol < d; bcol++) {
-                    const int jb = bcol >> 1, pb = bcol & 1, cb = L.act[jb];
-                    double hsum = 0.0;
-                    for (int g = 0; g < G; g++) {
-                        const double ma = pa ? L.net.Mim[g][ca] : L.net.Mre[g][ca];
-                        const double mb = pb ? L.net.Mim[g][cb] : L.net.Mre[g][cb];
-                        hsum += ma * L.kfree[g] * mb;
-                    }
-                    if (jb == ja) {
-                        const double z0 = L.z[ca][0], z1 = L.z[ca][1];
-                        const double nzc = sqrt(z0 * z0 + z1 * z1);
-                        const double za = (pa ? z1 : z0) / nzc, zb = (pb ? z1 : z0) / nzc;
-                        hsum += (L.net.mag[ca] / nzc) * ((pa == pb ? 1.0 : 0.0) - za * zb);
-                    }
-                    L.H[lane][bcol] = hsum;
-                    if (bcol == lane) diag = hsum;
-                }
-                // gradient component of this row
-                const double z0 = L.z[ca][0], z1 = L.z[ca][1];
-                const double nzc = sqrt(z0 * z0 + z1 * z1);
-                rhs = L.w[ca][pa] - L.net.mag[ca] * (pa ? z1 : z0) / nzc;
-                L.dir[lane] = diag;   // temporarily: diagonal, for the trace
+                const int ca = L.act[lane >> 1], pa = lane & 1;
+                rhs = L.w[ca][pa] - L.net.mag[ca] * L.zh[ca][pa];
             }
-            __syncthreads();
-            double tr = wave_sum_f64(lane < d ? L.dir[lane] : 0.0);
+            SOLVER_SYNC();
+            double tr = wave_sum_f64(lane < d ? L.H[lane][lane] : 0.0);
             double scale = tr / (double)d;
             scale = scale < 1e-12 ? 1e-12 : scale;
             if (lane < d) L.H[lane][lane] += mu * scale;
-            __syncthreads();
+            SOLVER_SYNC();
             const double grad_a = rhs;
-            solver_cholesky(L, d, lane, rhs);
+            long long cc = SOLVER_CLK(); t_build += cc - cb;
+            if (d == 2) solver_small<2>(L, lane, rhs);          // one active row: the usual case
+            else if (d == 4) solver_small<4>(L, lane, rhs);
+            else solver_cholesky(L, d, lane, rhs);
             const double dd0 = wave_sum_f64(lane < d ? grad_a * L.dir[lane] : 0.0);
 
+            long long cd = SOLVER_CLK(); t_chol += cd - cc;
             // line search on the sign of the directional derivative
             double alpha = 1.0;
             double dd = solver_trial(P, L, ln, lane, active, alpha);
@@ -358,7 +416,10 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
             // the pass of the last trial already left the state of the accepted point, unless that
             // trial was rejected
             if (!state_current) solver_pass(P, L, ln, lane, L.z);
+            t_ls += SOLVER_CLK() - cd;
         }
+        long long c2 = SOLVER_CLK();
+        SOLVER_STAT(9, c2 - c1); SOLVER_STAT(10, t_head); SOLVER_STAT(11, t_build); SOLVER_STAT(12, t_chol); SOLVER_STAT(13, t_ls);
         SOLVER_STAT(2, n_iter); SOLVER_STAT(3, n_trial); SOLVER_STAT(4, n_act); SOLVER_STAT(5, n_iter >= 20 ? 1 : 0);
         SOLVER_STAT(6, n_act == 1 ? 1 : 0); SOLVER_STAT(7, (!converged && !last_ok) ? 1 : 0);
         if (!converged && !last_ok) r.status |= EVC_STATUS_PROJ_NOCONV;
@@ -367,7 +428,8 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
         double y = ln.y;
         if (y != fmin(ln.b, ln.h)) y = tie_snap(y, ln.h);
         finish_step<WORDS>(P, io, L.net, lnet, env, lane, y, clamped, cur.acc, false, r);
-        __syncthreads();
+        SOLVER_STAT(14, SOLVER_CLK() - c2);
+        SOLVER_SYNC();
     }
 }
 

@@ -77,7 +77,8 @@ class Solver:
         nw = np.linalg.norm(w, axis=1)
         if np.all(nw <= r * (1 + tol)):
             return y, z, 0, True
-        mu = 1e-3
+        mu = getattr(self, 'mu0', 1e-3)
+        shrink = getattr(self, 'shrink', 0.25)
         for it in range(1, maxit + 1):
             g, nz, nw = self.grad(z, w)
             # activate violated rows with z = 0: tiny multiplier along w
@@ -147,7 +148,7 @@ class Solver:
                     alpha *= 0.5
                     nback += 1
                     zt, st, dd = trial(alpha)
-                mu = mu * 4.0 if nback > 1 else max(mu * 0.25, 1e-12)
+                mu = mu * 4.0 if nback > 1 else max(mu * shrink, 1e-12)
             z = zt
             y, S, k, w = st
         return y, z, maxit, False
@@ -158,6 +159,9 @@ def main():
     for net in (caltech_acn(), jpl_acn()):
         sol = Solver(net)
         sol.smart_start = '--smart' in sys.argv
+        for a in sys.argv:
+            if a.startswith('--mu0='): sol.mu0 = float(a[6:])
+            if a.startswith('--shrink='): sol.shrink = float(a[9:])
         print(net.site, 'G =', sol.G)
         n = net.num_stations
         worst = 0.0
