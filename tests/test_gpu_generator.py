@@ -98,3 +98,41 @@ def test_generate_requires_a_model_and_valid_slots():
     with pytest.raises(EngineError):
         eng.upload_gmm(bad)                      # 123 days > moer_days = 1
     eng.close()
+
+
+@pytest.mark.parametrize('site,period', [('jpl', 'Summer 2019'), ('caltech', 'Fall 2019')])
+def test_gmm_days_lean_kernels_match_oracle(site, period):
+    """A thousand device-generated GMM days through the lean kernels (no debug outputs: the streaming
+    kernel's production instantiation, all entry-slot counts, in-row water-filling, slow kernel), action
+    projection on, against the oracle replaying the downloaded tables: midday on these days is the
+    congested regime."""
+    from oracle.binding import OracleBatch, OracleNetwork
+    from sustaingym_amd.synthetic import synthetic_moer
+    N = 1024
+    net, tabs, eng = _engine(site, period, bank=N, N=N, project_action=True, debug_outputs=False)
+    n = net.num_stations
+    moer = synthetic_moer(tabs['num_days'], seed=3)
+    eng.upload_moer(moer, 0)
+    eng.generate_episodes(0, N, 99, 5000)
+    ns, sess, req, day, mp = eng.download_episodes(0, N)
+    ob = OracleBatch(OracleNetwork(net), N, 36, project=True)
+    ob.set_bank(ns, sess, req, day, moer)
+    slots = np.arange(N, dtype=np.int32)
+    assert np.array_equal(eng.reset(slots=slots, host=True), ob.reset(slots))
+    rng = np.random.default_rng(11)
+    slow, peak = 0, 0
+    for t in range(288):
+        a = rng.random((N, n)).astype(np.float32)
+        if t % 40 == 20:
+            a[::5] = 1.0                                     # greedy-like rows: feeders saturate
+        g = eng.step(a)
+        o = ob.step(a, debug=False)
+        assert np.array_equal(g['terminated'], o['terminated']), t
+        assert np.array_equal(g['obs'][:, n:2 * n], o['obs'][:, n:2 * n]), t          # est_departures
+        np.testing.assert_allclose(g['obs'], o['obs'], rtol=1e-6, atol=1e-6, err_msg=f't={t}')
+        np.testing.assert_allclose(g['reward'], o['reward'], rtol=1e-9, atol=1e-11, err_msg=f't={t}')
+        slow += eng.last_slow_count()
+        peak = max(peak, int((g['obs'][:, :n] > 0).sum(axis=1).max()))
+    assert g['terminated'].all() and slow > 0 and peak > 16
+    assert not (eng.env_scalars()['status'] & 2).any()       # EVC_STATUS_PROJ_NOCONV never raised
+    eng.close()
