@@ -3,10 +3,10 @@
 // Same wavefront geometry as evc_quad.h (4 DPP rows of 16 lanes, row r = environment 4*quad + r) but
 // the per-station arithmetic — action clip, demand cap, pilot rounding, battery charge, class sums —
 // runs over the environment's ENTRIES (the EVs plugged in right now), not over its 54-64 stations:
-// lane q of a row owns entries q, q+16, q+32, q+48 ("entry slots" c = 0..3).  A Caltech / JPL day has
-// <= 16 EVs plugged in at almost every step, so normally only entry slot 0 is live and slots 1-3 are
-// skipped by one wave-uniform branch; state traffic shrinks from 2 x 12 n bytes to 12 x 16 bytes read
-// plus 12 A written.  What stays station-shaped is the interface: the action row is read densely (range
+// lane q of a row owns entries q, q+16, q+32, q+48 ("entry slots" c = 0..3).  The iteration body exists
+// for 1, 2, 3 and 4 live entry slots and the widest row of the wavefront picks the copy: one slot (<= 16
+// EVs) on a quiet network and at night, two or three around midday of a real Caltech / JPL day.  State
+// traffic shrinks from 2 x 12 n bytes to 12 x 16 bytes read plus 12 A written.  What stays station-shaped is the interface: the action row is read densely (range
 // check) and exchanged to the entries through LDS; demands / est_departures of the observation are
 // scattered by the entries into a per-row LDS image and written out densely.
 //   * unplug = an entry with departure <= t+1 is simply not written back; survivors are packed by a
