@@ -63,10 +63,15 @@ struct SolverLane {
 __device__ __forceinline__ void solver_pass(const Params& P, SolverLds& L, SolverLane& ln, int lane,
                                             double (*zsrc)[2]) {
     const int m = P.m, G = P.G;
+    // rows that carry a multiplier at all (one or two, typically): nu sums over those only
+    unsigned long long zrows = __ballot(lane < m && (zsrc[lane < m ? lane : 0][0] != 0.0 || zsrc[lane < m ? lane : 0][1] != 0.0));
     if (lane < G) {
         double nu = 0.0;
-        for (int c = 0; c < m; c++)
+        while (zrows) {
+            const int c = __builtin_ctzll(zrows);
+            zrows &= zrows - 1ull;
             nu += L.net.Mre[lane][c] * zsrc[c][0] + L.net.Mim[lane][c] * zsrc[c][1];
+        }
         L.nu[lane] = nu;
     }
     SOLVER_SYNC();
@@ -89,7 +94,8 @@ __device__ __forceinline__ void solver_pass(const Params& P, SolverLds& L, Solve
     SOLVER_SYNC();
     if (lane < m) {
         double re = 0.0, im = 0.0;
-        for (int g = 0; g < G; g++) {
+#pragma unroll 4
+        for (int g = 0; g < G; g++) {             // unrolled: the LDS reads of a group are issued together
             re += L.net.Mre[g][lane] * L.S[g];
             im += L.net.Mim[g][lane] * L.S[g];
         }
@@ -196,7 +202,9 @@ __device__ __forceinline__ void solver_small(SolverLds& L, int lane, double rhs)
     for (int k = 0; k < D; k++) {
         double piv = A[k][k];
         piv = piv < 1e-300 ? 1e-300 : piv;
-        inv[k] = 1.0 / piv;
+        double rc0 = __builtin_amdgcn_rcp(piv);            // v_rcp_f64 + two Newton steps: the direction
+        rc0 = rc0 * (2.0 - piv * rc0);                     // need not be correctly rounded
+        inv[k] = rc0 * (2.0 - piv * rc0);
 #pragma unroll
         for (int i = k + 1; i < D; i++) {
             const double f = A[i][k] * inv[k];
