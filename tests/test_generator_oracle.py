@@ -91,3 +91,20 @@ def test_generator_matches_reference_distribution(site, period):
         assert np.max(np.abs(np.quantile(got, qs) - np.quantile(want, qs))) < 0.06 * (want.max() - want.min()) + 1.0
     tv = 0.5 * np.abs(bs / bs.sum() - rs / rs.sum()).sum()
     assert tv < 0.08, tv
+
+
+def test_generator_golden_vectors():
+    """tests/golden/generator_episodes.npz (made by tests/golden/make_generator_golden.py)."""
+    import os
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location('mgg', os.path.join(here, 'golden', 'make_generator_golden.py'))
+    mgg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgg)
+    gold = np.load(os.path.join(here, 'golden', 'generator_episodes.npz'))
+    for i, (site, period, seed, first, count) in enumerate(mgg.CASES):
+        tabs = gmm_device_tables(site, period)
+        ns, sess, req, day, mp = OracleGenerator(tabs, len(tabs['station_usage'])).episodes(seed, first, count, 128)
+        assert np.array_equal(ns, gold[f'ns_{i}']) and np.array_equal(day, gold[f'day_{i}'])
+        assert np.array_equal(sess.view(np.int16).reshape(count, 128, 4), gold[f'sess_{i}'])
+        assert np.array_equal(req.view(np.uint64), gold[f'req_{i}'].view(np.uint64))
+        assert np.array_equal(mp, gold[f'mp_{i}'])

@@ -136,3 +136,21 @@ def test_gmm_days_lean_kernels_match_oracle(site, period):
     assert g['terminated'].all() and slow > 0 and peak > 16
     assert not (eng.env_scalars()['status'] & 2).any()       # EVC_STATUS_PROJ_NOCONV never raised
     eng.close()
+
+
+def test_device_generator_reproduces_the_golden_episodes():
+    import os
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location('mgg', os.path.join(here, 'golden', 'make_generator_golden.py'))
+    mgg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgg)
+    gold = np.load(os.path.join(here, 'golden', 'generator_episodes.npz'))
+    for i, (site, period, seed, first, count) in enumerate(mgg.CASES):
+        net, tabs, eng = _engine(site, period, bank=count)
+        eng.generate_episodes(0, count, seed, first)
+        ns, sess, req, day, mp = eng.download_episodes(0, count)
+        assert np.array_equal(ns, gold[f'ns_{i}']) and np.array_equal(day, gold[f'day_{i}'])
+        assert np.array_equal(sess.view(np.int16).reshape(count, 128, 4), gold[f'sess_{i}'])
+        assert np.array_equal(req.view(np.uint64), gold[f'req_{i}'].view(np.uint64))
+        assert np.allclose(mp, gold[f'mp_{i}'], rtol=1e-13, atol=1e-12)
+        eng.close()
