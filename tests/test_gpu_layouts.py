@@ -71,3 +71,48 @@ def test_layouts_agree_step_for_step(site, busy, project):
     for key in ds:
         assert np.array_equal(ds[key], cs[key]), key
     dense.close(); comp.close()
+
+
+def test_status_word_and_entry_count_do_not_interfere():
+    """Compact layout keeps the entry count in the upper bits of the status word: host accessors must not
+    see it, clear_status / set_env_scalars must not destroy it, and stepping past the end of an episode
+    without autoreset must leave the entries alone."""
+    from sustaingym_amd import _lib
+    from sustaingym_amd.engine import StepEngine
+    net = caltech_acn()
+    N, n = 64, net.num_stations
+    wl = make_workload(net, N, seed=5, busy=True, stride=96)
+    os.environ['EVC_LAYOUT'] = 'compact'
+    try:
+        eng = StepEngine(net, N, project_action=True, autoreset=False, bank_slots=N, max_sessions=96, moer_days=3)
+    finally:
+        del os.environ['EVC_LAYOUT']
+    eng.upload_moer(wl['moer'], 0)
+    eng.upload_episodes(wl['n_sessions'], wl['sessions'], wl['requested'], wl['moer_day'], 0)
+    eng.reset(host=True)
+    rng = np.random.default_rng(0)
+    for t in range(150):
+        a = rng.random((N, n), dtype=np.float32)
+        if t == 100:
+            a[3, 5] = 1.5                              # out of range -> ACTION_CLAMPED on env 3
+        eng.step(a)
+    rem0, dep0, est0 = eng.station_state()
+    assert (dep0 >= 0).sum(axis=1).max() > 16          # entry counts well above one slot
+    sc = eng.env_scalars()
+    assert sc['status'][3] & _lib.STATUS_ACTION_CLAMPED and sc['status'].max() < 16     # flags only
+    _lib.check(eng.lib.evc_clear_status(eng.handle), 'evc_clear_status')
+    assert not eng.env_scalars()['status'].any()
+    rem1, dep1, est1 = eng.station_state()             # entries survived the status rewrite
+    assert np.array_equal(dep0, dep1) and np.array_equal(est0, est1) and np.array_equal(rem0, rem1)
+    out = eng.step(rng.random((N, n), dtype=np.float32))
+    assert not out['terminated'].any()
+    for t in range(151, 288):
+        out = eng.step(rng.random((N, n), dtype=np.float32))
+    assert out['terminated'].all()
+    rem2, dep2, est2 = eng.station_state()
+    out = eng.step(rng.random((N, n), dtype=np.float32))          # step after termination: no-op + flag
+    assert out['terminated'].all() and not out['reward'].any()
+    assert (eng.env_scalars()['status'] & _lib.STATUS_STEP_AFTER_DONE).all()
+    rem3, dep3, est3 = eng.station_state()
+    assert np.array_equal(dep2, dep3) and np.array_equal(rem2, rem3)
+    eng.close()
