@@ -5,7 +5,7 @@ Public surface (mirrors ``sustaingym.envs.evcharging``):
     EVChargingEnv, MultiAgentEVChargingEnv, DiscreteActionWrapper      (reference API)
     EVChargingVectorEnv, SB3VecEnv                                      (batched API)
     RealTraceGenerator, GMMsTraceGenerator, BatchedGMMTraceGenerator,
-    DeviceGMMTraceGenerator                                             (episode generators)
+    DeviceGMMTraceGenerator, RealTraceBank                              (episode generators)
     StepEngine                                                          (C-ABI handle)
     BatteryDispatchVectorEnv                                            (config 4, synthetic: battery.py)
 
@@ -15,7 +15,7 @@ need a GPU, constructing an environment does.
 from .network import ChargingNetwork, caltech_acn, jpl_acn, site_str_to_site  # noqa: F401
 from .event_generation import (AbstractTraceGenerator, BatchedGMMTraceGenerator,  # noqa: F401
                                DeviceGMMTraceGenerator, EventTable, GMMsTraceGenerator, MOERLoader,
-                               RealTraceGenerator)
+                               RealTraceBank, RealTraceGenerator)
 
 
 def __getattr__(name):

@@ -23,7 +23,7 @@ import numpy as np
 from . import spaces
 from .engine import StepEngine
 from .event_generation import (AbstractTraceGenerator, BatchedGMMTraceGenerator, DeviceGMMTraceGenerator,
-                               EventTable)
+                               EventTable, RealTraceBank)
 from .network import site_str_to_site
 
 try:  # pragma: no cover
@@ -322,7 +322,8 @@ class EVChargingVectorEnv:
     boundary are drawn in one vectorised call on a worker thread while the GPU plays the current
     episodes (~50 us per episode instead of ~2 ms through N per-environment generators).  With a
     :class:`DeviceGMMTraceGenerator` the bank is refilled by the GPU itself (``evc_generate_episodes``,
-    ~10 ns per episode) and only the ``max_profit`` values travel to the host.
+    ~10 ns per episode) and only the ``max_profit`` values travel to the host.  A :class:`RealTraceBank`
+    keeps every real day of the period resident and walks the days sequentially inside the kernel.
 
     ``output='numpy'`` (default) returns host arrays (SB3 / RLLib); ``'torch'`` takes and returns
     device tensors without leaving the GPU."""
@@ -334,7 +335,8 @@ class EVChargingVectorEnv:
         assert output in ('numpy', 'torch')
         self._batched = data_generators if isinstance(data_generators, BatchedGMMTraceGenerator) else None
         self._devgen = data_generators if isinstance(data_generators, DeviceGMMTraceGenerator) else None
-        if self._batched is not None or self._devgen is not None:
+        self._realbank = data_generators if isinstance(data_generators, RealTraceBank) else None
+        if self._batched is not None or self._devgen is not None or self._realbank is not None:
             assert num_envs is not None, 'num_envs is required with a batched / device generator'
             gens = [data_generators] * num_envs
         elif callable(data_generators):
@@ -362,17 +364,24 @@ class EVChargingVectorEnv:
         self.action_space = self.single_action_space
         self._ndays = g0.num_days_in_date_range
         self._day0 = g0.date_range[0]
+        if self._realbank is not None:
+            max_sessions = self._stride = self._realbank.sessions.shape[1]
+        self._bank_slots = self._ndays if self._realbank is not None else 2 * N
         self._engine = StepEngine(self.cn, N, moer_forecast_steps=k, project_action=project_action_in_env,
-                                  autoreset=True, device=device, bank_slots=2 * N,
+                                  autoreset=True, device=device, bank_slots=self._bank_slots,
                                   max_sessions=max_sessions, moer_days=self._ndays)
         from datetime import timedelta
         moer = np.stack([g0.moer_loader.retrieve(self._day0 + timedelta(days=d)) for d in range(self._ndays)])
         self._engine.upload_moer(moer, 0)
-        self._engine.set_autoreset_stride(N)
+        self._engine.set_autoreset_stride(1 if self._realbank is not None else N)
         if self._devgen is not None:
             self._engine.upload_gmm(self._devgen.tables)
+        if self._realbank is not None:                 # the whole period, once
+            b = self._realbank
+            self._engine.upload_episodes(b.n_sessions, b.sessions, b.requested, b.moer_day, 0)
         self._slices = obs_slices(n, k)
-        self._max_profit = np.zeros(2 * N)            # per bank slot
+        self._max_profit = (self._realbank.max_profit.copy() if self._realbank is not None
+                            else np.zeros(2 * N))     # per bank slot
         self._cur_slot = np.arange(N)                 # slot each env is playing
         self._episodes = np.zeros(N, dtype=np.int64)
         self._steps_in_episode = 0                    # all environments run in lock-step (288 steps)
@@ -476,12 +485,17 @@ class EVChargingVectorEnv:
             gens_seed = int(seed) if np.isscalar(seed) else int(seeds[0])
             (self._batched or self._devgen).set_seed(gens_seed)
         self._steps_in_episode = 0
-        self._stage(ids, ids, seeds)                  # current episodes -> slots [0, N)
-        self._stage(ids, ids + N, [None] * N)         # next episodes   -> slots [N, 2N)
-        self._cur_slot = ids.copy()
+        if self._realbank is not None:
+            # RealTraceGenerator.set_seed with sequential days: day = (seed mod D); None -> 0
+            first = np.array([0 if sd is None else int(sd) for sd in seeds], dtype=np.int64) % self._ndays
+            self._cur_slot = first
+        else:
+            self._stage(ids, ids, seeds)                  # current episodes -> slots [0, N)
+            self._stage(ids, ids + N, [None] * N)         # next episodes   -> slots [N, 2N)
+            self._cur_slot = ids.copy()
         self._info_max_profit = None
         host = self.output == 'numpy'
-        obs = self._engine.reset(slots=ids, host=host)
+        obs = self._engine.reset(slots=self._cur_slot.astype(np.int32), host=host)
         if host:
             obs = obs.copy()
         return self._wrap_obs(obs), self._infos(None, None)
@@ -538,11 +552,14 @@ class EVChargingVectorEnv:
             done_mask = np.ones(N, dtype=bool)
             self._final_max_profit = self._max_profit[self._cur_slot]
             vacated = self._cur_slot.copy()
-            self._cur_slot = (vacated + N) % (2 * N)          # kernel autoreset: slot + stride
+            step_slots = 1 if self._realbank is not None else N
+            self._cur_slot = (vacated + step_slots) % self._bank_slots     # kernel autoreset: slot + stride
             self._info_max_profit = None
             self._episodes += 1
             self._steps_in_episode = 0
-            if self._devgen is not None:
+            if self._realbank is not None:
+                pass                                           # the next day is already in the bank
+            elif self._devgen is not None:
                 self._stage_device(vacated)                    # one kernel launch, no host sampling
             elif self._batched is not None:
                 self._stage_batched(vacated, background=True)  # overlaps the next episode's steps

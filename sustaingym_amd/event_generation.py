@@ -531,3 +531,47 @@ class DeviceGMMTraceGenerator:
             seed = int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).view(np.uint64)[0])
         self.seed = int(seed) & (2 ** 64 - 1)
         self.next_episode = 0
+
+
+class RealTraceBank:
+    """Every day of a packaged period as one resident episode bank (``RealTraceGenerator`` with
+    ``sequential=True``, the reference default, for a whole batch of environments).
+
+    Pass it to ``EVChargingVectorEnv`` (with ``num_envs``): the tables of all ``D`` days are uploaded once,
+    environment ``i`` starts on day ``(seed + i) mod D`` (``RealTraceGenerator.set_seed``,
+    event_generation.py:273-282) and moves to the next day at every episode boundary inside the kernel
+    (``_update_day`` :284-291, cycling at the end of the period) — no host work at boundaries.  As in
+    the reference the MOER of an episode is that of the *advanced* day (env.py:321-323 calls
+    ``get_moer`` after ``get_event_queue``).
+
+    Deviation, on purpose: the reference's ``reset()`` re-seeds its generator with ``None`` at every
+    un-seeded reset (env.py:314), which rewinds a sequential generator to the first day
+    (event_generation.py:278-281) — under a VectorEnv autoreset every episode after the first would replay
+    day 0.  The bank implements the documented intent (``_update_day``: "increments day"); an episode on
+    day ``d`` equals the reference's ``reset(seed=d)``.  ``EVChargingVectorEnv`` fed with one
+    ``RealTraceGenerator`` per environment keeps the reference's literal behaviour."""
+
+    def __init__(self, site: str, date_period, use_unclaimed: bool = False, requested_energy_cap: float = 100,
+                 max_sessions: int = 128):
+        g = RealTraceGenerator(site, date_period, sequential=True, use_unclaimed=use_unclaimed,
+                               requested_energy_cap=requested_energy_cap)
+        self.site = site
+        self.date_range_str = g.date_range_str
+        self.date_range = g.date_range
+        self.num_days_in_date_range = D = g.num_days_in_date_range
+        self.requested_energy_cap = requested_energy_cap
+        self.moer_loader = g.moer_loader
+        self.num_stations = g.num_stations
+        self.n_sessions = np.zeros(D, np.int32)
+        self.sessions = np.zeros((D, max_sessions), dtype=SESSION_DTYPE)
+        self.requested = np.zeros((D, max_sessions))
+        self.max_profit = np.zeros(D)
+        for d in range(D):
+            g.set_seed(d)                                   # day = first day + d
+            t = g.get_event_table()
+            assert len(t) <= max_sessions, f'day {d} has {len(t)} sessions'
+            self.n_sessions[d] = len(t)
+            self.sessions[d, :len(t)] = t.sessions
+            self.requested[d, :len(t)] = t.requested
+            self.max_profit[d] = t.max_profit()
+        self.moer_day = ((np.arange(D) + 1) % D).astype(np.int32)     # MOER of the advanced day

@@ -361,3 +361,37 @@ def test_vector_env_device_generation_matches_oracle_generator_and_step():
                 _, r = o.step(acts[ep * 288 + t, e])
                 assert abs(r.reward - g_rew[ep * 288 + t, e]) <= 1e-5 * max(1.0, abs(r.reward))
     venv.close()
+
+
+@pytest.mark.gpu
+def test_vector_env_real_trace_bank_walks_the_days():
+    """RealTraceBank (all days of the period resident, days walked inside the kernel): environment i plays
+    days (seed + i), (seed + i) + 1, ... mod D; each of those episodes equals a single EVChargingEnv on a
+    sequential RealTraceGenerator reset with that day as seed (the reference's way of selecting a day)."""
+    from sustaingym_amd.envs import EVChargingEnv, EVChargingVectorEnv
+    from sustaingym_amd.event_generation import RealTraceBank, RealTraceGenerator
+    N, D = 5, 7
+    period = ('2019-05-28', '2019-06-03')                  # 7 days: the walk wraps around
+    venv = EVChargingVectorEnv(RealTraceBank('caltech', period), num_envs=N, project_action_in_env=False)
+    single = EVChargingEnv(RealTraceGenerator('caltech', period, sequential=True), project_action_in_env=False)
+    obs, info = venv.reset(seed=4)
+    rng = np.random.default_rng(0)
+    acts = rng.random((3 * 288, N, 54)).astype(np.float32)
+    v_obs, v_rew, v_mp = [], [], []
+    for t in range(3 * 288):
+        v_mp.append(info['max_profit'].copy())
+        obs, rew, term, _, info = venv.step(acts[t])
+        assert term.all() == (t % 288 == 287)
+        v_obs.append({k: v.copy() for k, v in (info['final_observation'] if term.all() else obs).items()})
+        v_rew.append(rew.copy())
+    for i in (0, 3, 4):
+        for ep in range(3):
+            day = (4 + i + ep) % D
+            o, inf = single.reset(seed=day)
+            assert abs(inf['max_profit'] - v_mp[ep * 288][i]) < 1e-9
+            for t in range(288):
+                o, r, term, _, inf = single.step(acts[ep * 288 + t, i])
+                assert r == v_rew[ep * 288 + t][i], (i, ep, t)
+                for key in o:
+                    assert np.array_equal(np.ravel(o[key]), np.ravel(v_obs[ep * 288 + t][key][i])), (i, ep, t, key)
+    venv.close(); single.close()
