@@ -159,6 +159,7 @@ def main():
                     'achieved': round(achieved, 2),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
                     'traffic': traffic, 'state_layout': layout, 'avg_kernel_ms': round(avg_main, 5),
+                    'traffic_gbs': (round(traffic / (avg_main * 1e-3) / 1e9, 2) if traffic else None),
                     'solver_kernel_ms': round(avg_slow, 5),
                     'slow_queue_envs_per_step': (round(float(np.mean(slow_cnt)), 1) if slow_cnt else 0.0),
                     'algorithmic_bytes_per_launch': bytes_per_launch}
