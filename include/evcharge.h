@@ -33,6 +33,7 @@
 #ifndef EVCHARGE_H
 #define EVCHARGE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -233,6 +234,12 @@ int evc_gather_agent_obs(evc_engine* e, const float* obs_dev, const float* delay
 
 /* Host-buffer convenience variants (synchronous; staged through pinned memory).  Any
  * output pointer may be NULL. */
+/* Page-locks (hipHostRegister) caller-owned host buffers used with the *_host entry points: the
+ * device<->host copies of evc_step_host / evc_reset_host then run at PCIe speed (pageable buffers work
+ * too, several times slower).  Unregister before the memory is freed. */
+int evc_host_register(void* ptr, size_t bytes);
+int evc_host_unregister(void* ptr);
+
 int evc_reset_host(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_t* slots,
                    float* obs_host);
 int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, int32_t bins,

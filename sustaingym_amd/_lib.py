@@ -79,6 +79,8 @@ SIGNATURES = {
     'evc_step': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
     'evc_rollout': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(StepOut)]),
     'evc_gather_agent_obs': (_i32, [_vp, _vp, _vp, _vp]),
+    'evc_host_register': (_i32, [_vp, C.c_size_t]),
+    'evc_host_unregister': (_i32, [_vp]),
     'evc_reset_host': (_i32, [_vp, _vp, _i32, _vp, _vp]),
     'evc_step_host': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
     'evc_get_env_scalars': (_i32, [_vp, _vp]),

@@ -723,6 +723,17 @@ int evc_reset_host(evc_engine* e, const int32_t* env_ids, int32_t count, const i
     return EVC_OK;
 }
 
+int evc_host_register(void* ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail(EVC_EINVAL, "evc_host_register: bad argument");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return EVC_OK;
+}
+
+int evc_host_unregister(void* ptr) {
+    if (ptr) HIP_TRY(hipHostUnregister(ptr));
+    return EVC_OK;
+}
+
 int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, int32_t bins,
                   const evc_step_out* oh) {
     if (!e || !oh || (!actions_host && action_kind != EVC_ACTION_GREEDY))
@@ -744,9 +755,16 @@ int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, 
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (oh->obs) HIP_TRY(hipMemcpy(oh->obs, e->d_obs, sizeof(float) * N * F, hipMemcpyDeviceToHost));
     if (oh->reward) HIP_TRY(hipMemcpy(oh->reward, e->d_reward, sizeof(double) * N, hipMemcpyDeviceToHost));
-    if (oh->terminated) HIP_TRY(hipMemcpy(oh->terminated, e->d_term, N, hipMemcpyDeviceToHost));
+    bool any_done = true;
+    if (oh->terminated) {
+        HIP_TRY(hipMemcpy(oh->terminated, e->d_term, N, hipMemcpyDeviceToHost));
+        any_done = false;
+        for (size_t i = 0; i < N && !any_done; i++) any_done = oh->terminated[i] != 0;
+    }
     if (oh->breakdown) HIP_TRY(hipMemcpy(oh->breakdown, e->d_breakdown, sizeof(double) * N * 3, hipMemcpyDeviceToHost));
-    if (oh->final_obs) HIP_TRY(hipMemcpy(oh->final_obs, e->d_final, sizeof(float) * N * F, hipMemcpyDeviceToHost));
+    // terminal observations exist only on steps that end an episode: no N x F copy on the other 287
+    if (oh->final_obs && any_done)
+        HIP_TRY(hipMemcpy(oh->final_obs, e->d_final, sizeof(float) * N * F, hipMemcpyDeviceToHost));
     if (oh->pilots) HIP_TRY(hipMemcpy(oh->pilots, e->d_pilots, sizeof(double) * N * n, hipMemcpyDeviceToHost));
     if (oh->rates) HIP_TRY(hipMemcpy(oh->rates, e->d_rates, sizeof(double) * N * n, hipMemcpyDeviceToHost));
     if (oh->projected) HIP_TRY(hipMemcpy(oh->projected, e->d_proj, sizeof(double) * N * n, hipMemcpyDeviceToHost));

@@ -59,12 +59,16 @@ class StepEngine:
                                   C.byref(handle)), 'evc_create')
         self.handle = handle
         self._dev_out: dict[str, Any] | None = None
-        self._host_out: dict[str, np.ndarray] | None = None
+        self._host_out = None
+        self._registered: list[np.ndarray] = []
         self._returns = None
 
     # ------------------------------------------------------------------ lifecycle
     def close(self) -> None:
         if getattr(self, 'handle', None):
+            for arr in getattr(self, '_registered', []):      # arrays stay valid (pageable again)
+                self.lib.evc_host_unregister(C.c_void_p(arr.ctypes.data))
+            self._registered = []
             self.lib.evc_destroy(self.handle)
             self.handle = None
 
@@ -292,19 +296,34 @@ class StepEngine:
         check(self.lib.evc_step_host(self.handle, None, _lib.ACTION_GREEDY, 0, C.byref(so)), 'evc_step_host')
         return out
 
+    def _pinned(self, shape, dtype) -> np.ndarray:
+        """numpy-owned array, page-locked for the lifetime of the engine (evc_host_register): device<->host
+        copies at PCIe speed.  Falls back to pageable memory if registration is refused."""
+        arr = np.zeros(shape, dtype=dtype)
+        if arr.nbytes and self.lib.evc_host_register(C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes)) == 0:
+            self._registered.append(arr)
+        return arr
+
     def _host_buffers(self) -> dict[str, np.ndarray]:
+        """Two alternating sets of page-locked output arrays: what a step returns stays valid until the
+        step after the next one (callers that keep observations longer copy them, as RL libraries do)."""
         if self._host_out is None:
             N, n, F = self.N, self.n, self.F
-            out = {
-                'obs': np.zeros((N, F), np.float32), 'reward': np.zeros(N, np.float64),
-                'terminated': np.zeros(N, np.uint8), 'breakdown': np.zeros((N, 3), np.float64),
-                'final_obs': np.zeros((N, F), np.float32),
-            }
-            if self.debug_outputs:
-                for key in ('pilots', 'rates', 'projected'):
-                    out[key] = np.zeros((N, n), np.float64)
-            self._host_out = out
-        return self._host_out
+            sets = []
+            for _ in range(2):
+                out = {
+                    'obs': self._pinned((N, F), np.float32), 'reward': self._pinned((N,), np.float64),
+                    'terminated': self._pinned((N,), np.uint8), 'breakdown': self._pinned((N, 3), np.float64),
+                    'final_obs': self._pinned((N, F), np.float32),
+                }
+                if self.debug_outputs:
+                    for key in ('pilots', 'rates', 'projected'):
+                        out[key] = self._pinned((N, n), np.float64)
+                sets.append(out)
+            self._host_out = sets
+            self._host_flip = 0
+        self._host_flip ^= 1
+        return self._host_out[self._host_flip]
 
     def _step_host(self, actions: np.ndarray, bins: int):
         assert actions.shape == (self.N, self.n)

@@ -527,8 +527,8 @@ class EVChargingVectorEnv:
             out = self._engine.step(np.ascontiguousarray(actions), bins=bins)
             term = out['terminated'].astype(bool)
             assert bool(term.all()) == boundary == bool(term.any())
-            out = {k: (v.copy() if k in ('obs', 'reward', 'breakdown') or (k == 'final_obs' and boundary) else v)
-                   for k, v in out.items()}
+            # the engine alternates between two sets of page-locked output arrays: what this call returns
+            # stays valid until the step after the next one
             truncated = np.zeros(N, dtype=bool)
         else:
             import torch
