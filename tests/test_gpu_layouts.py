@@ -116,3 +116,35 @@ def test_status_word_and_entry_count_do_not_interfere():
     rem3, dep3, est3 = eng.station_state()
     assert np.array_equal(dep2, dep3) and np.array_equal(rem2, rem3)
     eng.close()
+
+
+@pytest.mark.parametrize('k', [1, 12])
+@pytest.mark.parametrize('layout', ['compact', 'dense'])
+def test_short_moer_forecasts(k, layout):
+    """moer_forecast_steps below the default 36 (env.py:120 allows 1..36): observation width 2n + k + 2,
+    forecast columns 1..k of the MOER matrix; against the oracle, debug and production kernels."""
+    from helpers import assert_step_parity, make_pair
+    net = caltech_acn()
+    N, n = 40, net.num_stations
+    wl = make_workload(net, N, seed=2)
+    old = os.environ.get('EVC_LAYOUT')
+    os.environ['EVC_LAYOUT'] = layout
+    try:
+        eng, ob = make_pair(net, N, wl, project=True, autoreset=True, k=k, debug=True)
+        lean, _ = make_pair(net, N, wl, project=True, autoreset=True, k=k, debug=False)
+    finally:
+        if old is None:
+            del os.environ['EVC_LAYOUT']
+        else:
+            os.environ['EVC_LAYOUT'] = old
+    assert eng.F == 2 * n + k + 2
+    assert np.array_equal(eng.reset(host=True), ob.reset())
+    lean.reset(host=True)
+    rng = np.random.default_rng(k)
+    for t in range(300):
+        a = rng.random((N, n), dtype=np.float32)
+        g, o, l = eng.step(a), ob.step(a, autoreset=True), lean.step(a)
+        assert g['obs'].shape == (N, 2 * n + k + 2)
+        assert_step_parity(g, o, n, tag=f'k={k} t={t}')
+        assert np.array_equal(l['obs'], g['obs']) and np.array_equal(l['terminated'], g['terminated'])
+    eng.close(); lean.close()
