@@ -200,3 +200,45 @@ def test_checkpoint_roundtrip(caltech):
         for key in ref:
             assert np.array_equal(out[key], ref[key]), key
     eng.close()
+
+
+@pytest.mark.parametrize('layout', ['compact', 'dense'])
+def test_many_short_sessions_and_simultaneous_arrivals(caltech, layout, monkeypatch):
+    """Days with up to 250 one-to-three-step sessions (session capacity 256): the event cursor goes far
+    beyond 128, up to a whole network of EVs plugs in at the same step, stations are re-used right after
+    an unplug (unplug-before-plug at equal timestamps)."""
+    from sustaingym_amd._lib import SESSION_DTYPE
+    from sustaingym_amd.synthetic import synthetic_moer
+    monkeypatch.setenv('EVC_LAYOUT', layout)
+    n, N, S = caltech.num_stations, 24, 256
+    rng = np.random.default_rng(17)
+    ns = np.zeros(N, np.int32)
+    sess = np.zeros((N, S), dtype=SESSION_DTYPE)
+    req = np.zeros((N, S))
+    for e in range(N):
+        free_from = np.zeros(n, dtype=int)              # first pass at which each EVSE can take a new EV
+        rows = []
+        t = 1
+        while t < 280 and len(rows) < 250:
+            burst = rng.integers(1, n + 1) if rng.random() < 0.15 else rng.integers(0, 4)
+            for st in rng.permutation(n)[:burst]:
+                if free_from[st] <= t and len(rows) < 250:
+                    d = t + int(rng.integers(1, 4))
+                    rows.append((t, min(d, 287), min(d + int(rng.integers(0, 3)), 287), st, rng.uniform(0.2, 3.0)))
+                    free_from[st] = max(min(d, 287), t + 1)
+            t += int(rng.integers(1, 3))
+        rows.sort(key=lambda r: r[0])
+        ns[e] = len(rows)
+        for j, (a, d, es, st, rq) in enumerate(rows):
+            sess[e, j] = (a, d, max(es, a + 1), st)
+            req[e, j] = rq
+    assert ns.max() > 200
+    wl = dict(n_sessions=ns, sessions=sess, requested=req, moer_day=np.zeros(N, np.int32), moer=synthetic_moer(1, seed=4))
+    eng, ob = make_pair(caltech, N, wl, project=True)
+    assert np.array_equal(eng.reset(host=True), ob.reset())
+    for t in range(288):
+        a = rng.random((N, n), dtype=np.float32)
+        assert_step_parity(eng.step(a), ob.step(a), n, tag=f'{layout} t={t}')
+    assert not eng.env_scalars()['status'].any()         # no StationOccupied, no clamping
+    assert (eng.env_scalars()['cursor'] == ns).all()
+    eng.close()
