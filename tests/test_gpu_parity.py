@@ -242,3 +242,22 @@ def test_many_short_sessions_and_simultaneous_arrivals(caltech, layout, monkeypa
     assert not eng.env_scalars()['status'].any()         # no StationOccupied, no clamping
     assert (eng.env_scalars()['cursor'] == ns).all()
     eng.close()
+
+
+def test_discrete_actions_batched(caltech):
+    """DiscreteActionWrapper.action (wrappers.py:43-45) for a whole batch: int64 {0..4} actions through
+    the discretise pre-kernel and the production kernels, projection on."""
+    N, n = 300, caltech.num_stations
+    wl = make_workload(caltech, N, seed=23)
+    eng, ob = make_pair(caltech, N, wl, project=True, debug=False)
+    assert np.array_equal(eng.reset(host=True), ob.reset())
+    rng = np.random.default_rng(5)
+    for t in range(288):
+        a = rng.integers(0, 5, (N, n), dtype=np.int64)
+        g = eng.step(a, bins=5)
+        o = ob.step(a, bins=5, debug=False)
+        assert np.array_equal(g['terminated'], o['terminated'])
+        assert np.array_equal(g['obs'][:, n:2 * n], o['obs'][:, n:2 * n])
+        np.testing.assert_allclose(g['obs'], o['obs'], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(g['reward'], o['reward'], rtol=1e-9, atol=1e-11)
+    eng.close()
