@@ -75,8 +75,7 @@ struct EnvRegs {
     int t, cursor, slot, moer_day, n_sessions, next_arrival, status, episodes;
 };
 
-// Raw loads of one environment's rows, issued ahead of use (software prefetch: while the wave
-// computes environment e, the rows of its next environment are already in flight).
+// Raw loads of one environment's rows.
 struct EnvLoads {
     int4 s0, s1;      // env scalars (uniform address, broadcast)
     double rem;       // remaining-demand row element
@@ -422,14 +421,8 @@ struct EnvWalker {
 // main step kernel: handles every environment whose projection is the box clip (always the case
 // with project_action_in_env=False); the others are queued for the solver kernel.
 // ------------------------------------------------------------------------------------------
-#ifndef EVC_MIN_WAVES
-#define EVC_MIN_WAVES 1
-#endif
-#ifndef EVC_PREFETCH
-#define EVC_PREFETCH 0
-#endif
 template <bool PROJECT, int WORDS>
-__global__ __launch_bounds__(256, EVC_MIN_WAVES) void step_kernel(Params P, StepIO io) {
+__global__ __launch_bounds__(256) void step_kernel(Params P, StepIO io) {
     __shared__ LdsNet net;
     stage_net(net, P);
     const int lane = threadIdx.x & 63;
@@ -437,33 +430,12 @@ __global__ __launch_bounds__(256, EVC_MIN_WAVES) void step_kernel(Params P, Step
     const LaneNet ln = lane_net(P, lane);
     EnvWalker walk(P.N, 4);
     if (walk.first >= walk.hi) return;
-#if EVC_PREFETCH
-    EnvLoads nxt = issue_loads(P, io, walk.first, lane);
-#endif
     for (int env = walk.first; env < walk.hi; env += walk.stride) {
-#if EVC_PREFETCH
-        const EnvLoads cur = nxt;
-        if (env + walk.stride < walk.hi) nxt = issue_loads(P, io, env + walk.stride, lane);
-#else
         const EnvLoads cur = issue_loads(P, io, env, lane);
-#endif
         EnvRegs r;
         unpack_env(cur, r);
         bool clamped;
         const double a = unpack_action(io, cur, clamped);
-#ifdef EVC_ABL_COPY
-        {
-            r.t += 1; r.rem += a;
-            float mv = moer_obs_value(P, lane, r.moer_day, r.t);
-            buf_st_f64(row_rsrc(io.out.reward + env, 8u), lane * 8u, a);
-            buf_st_u8(row_rsrc(io.out.terminated + env, 1u), lane, 0);
-            if (io.out.breakdown) buf_st_f64(row_rsrc(io.out.breakdown + (size_t)env * 3, 24u), lane * 8u, cur.acc);
-            write_obs(P, io.out.obs + (size_t)env * P.F, lane, r, mv);
-            buf_st_f64(row_rsrc(P.acc + (size_t)env * 3, 24u), lane * 8u, cur.acc + a);
-            store_env(P, env, lane, r);
-            continue;
-        }
-#endif
         if (r.t >= EVC_EPISODE_STEPS) {            // step() after termination without autoreset
             if (lane == 0) {
                 P.scal[2 * env + 1].z = cur.s1.z | EVC_STATUS_STEP_AFTER_DONE;   // keeps the entry count

@@ -156,9 +156,6 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
     }
 }
 
-#ifndef EVC_QUAD_PREFETCH
-#define EVC_QUAD_PREFETCH 0
-#endif
 #ifndef EVC_QUAD_WAVES
 #define EVC_QUAD_WAVES 4
 #endif
@@ -232,18 +229,11 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
         L.acc = buf_ld_f64(r_acc, (ev_ && q < 3u) ? env_ * 24u + q * 8u : kOob);
         return L;
     };
-#if EVC_QUAD_PREFETCH
-    QuadLoads nxt = issue(walk.first);
-#endif
     for (int quad = walk.first; quad < walk.hi; quad += walk.stride) {
         const unsigned env = (unsigned)quad * 4u + row;
         const bool ev = env < N;
-#if EVC_QUAD_PREFETCH
-        const QuadLoads cur = nxt;
-        nxt = issue(quad + walk.stride);     // rows of the next quad are in flight while this one computes
-#else
+        // (a register prefetch of the next quad costs this kernel a wave of occupancy: measured slower)
         const QuadLoads cur = issue(quad);
-#endif
         const v4u s0 = cur.s0, s1 = cur.s1;
         double rem[kSlots];
         int dep[kSlots], est[kSlots];
