@@ -48,6 +48,11 @@ def parse_args():
     p.add_argument('--episodes', default='synthetic', choices=['synthetic', 'gmm'],
                    help="'gmm': the bank is generated on the device from the reference's GMM (Summer 2019) - busier\n"
                         'days than the synthetic default; not the headline')
+    p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                   help="process-group backend for --gpus > 1 ('nccl' = RCCL; 'gloo' only to exercise the N > 1\n"
+                        'logic with several ranks on ONE GPU, see --single-device)')
+    p.add_argument('--single-device', action='store_true',
+                   help='testing aid: every rank uses cuda:0 (needs --backend gloo)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-envs', type=int, default=2048)
     p.add_argument('--cpu-steps', type=int, default=96)
@@ -65,12 +70,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if args.single_device:
+            assert args.backend == 'gloo', '--single-device needs --backend gloo (RCCL wants one GPU per rank)'
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
     else:
         dist = None
         torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    coll_dev = dev if (world == 1 or args.backend == 'nccl') else torch.device('cpu')   # where collectives run
 
     from sustaingym_amd.distributed import all_gather_metrics, max_over_ranks, metrics_vector
     from sustaingym_amd.engine import StepEngine
@@ -118,7 +130,7 @@ def main():
     for i in range(args.steps):
         step(ptrs[i % len(ptrs)])
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, coll_dev)
 
     # ---- metrics all-gather (the only collective of the path; off the step critical path) ----
     # The accumulators are per running episode (env.py:329-338 zeroes them at reset) and the default
@@ -126,7 +138,7 @@ def main():
     tail = (144 - (args.warmup + args.steps) % 288) % 288
     for i in range(tail):
         step(ptrs[i % len(ptrs)])
-    _, total = all_gather_metrics(metrics_vector(eng.read_metrics()), dev)
+    _, total = all_gather_metrics(metrics_vector(eng.read_metrics()), coll_dev)
 
     # ---- per-kernel duration with HIP events on the engine's stream (rank 0) ----
     roofline = None
