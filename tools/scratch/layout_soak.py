@@ -1,0 +1,29 @@
+# Dense vs compact layout at N = 65536 on GMM days (projection on), every step compared on the device.
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from sustaingym_amd.engine import StepEngine
+from sustaingym_amd.network import site_str_to_site
+from sustaingym_amd.event_generation import gmm_device_tables
+from sustaingym_amd.synthetic import synthetic_moer
+site = sys.argv[1] if len(sys.argv) > 1 else 'jpl'
+net = site_str_to_site(site); N, n = 65536, net.num_stations
+tabs = gmm_device_tables(site, 'Summer 2019')
+moer = synthetic_moer(tabs['num_days'], seed=7)
+def make(layout):
+    os.environ['EVC_LAYOUT'] = layout
+    e = StepEngine(net, N, project_action=True, autoreset=True, bank_slots=8192, max_sessions=128, moer_days=tabs['num_days'])
+    e.upload_moer(moer); e.upload_gmm(tabs); e.generate_episodes(0, 8192, 1, 0); e.reset()
+    return e
+a, b = make('dense'), make('compact')
+g = torch.Generator(device='cuda'); g.manual_seed(1)
+ring = [torch.rand((N, n), device='cuda', generator=g) for _ in range(8)]
+worst_r, worst_o, bad_int, peak = 0.0, 0.0, 0, 0
+for t in range(300):
+    oa = {k: v.clone() for k, v in a.step(ring[t % 8]).items()}
+    ob = b.step(ring[t % 8])
+    bad_int += int((oa['terminated'] != ob['terminated']).sum()) + int((oa['obs'][:, n:2*n] != ob['obs'][:, n:2*n]).sum())
+    worst_r = max(worst_r, float(((oa['reward'] - ob['reward']).abs() / oa['reward'].abs().clamp_min(1e-3)).max()))
+    worst_o = max(worst_o, float((oa['obs'] - ob['obs']).abs().max()))
+    peak = max(peak, int((ob['obs'][:, :n] > 0).sum(dim=1).max()))
+print(f'{site}: integer mismatches {bad_int}, worst relative reward diff {worst_r:.2e}, worst obs diff {worst_o:.2e}, peak EVs in one env {peak}, status census {int((b.env_scalars()["status"] != 0).sum())}')
