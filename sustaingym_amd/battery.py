@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check
+
 
 EPISODE_STEPS, TRACE_LEN = 288, 289
 
