@@ -80,20 +80,16 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
 #pragma unroll
     for (int j = 0; j < kSlots; j++) st_valid[j] = (unsigned)j * 16u + q < n;
 
-    const rsrc_t r_rem = row_rsrc(P.rem, N * n * 8u);
-    const rsrc_t r_de = row_rsrc(P.depest, N * n * 4u);
+    const rsrc_t r_win = row_rsrc(P.win_base, P.win_span);      // every engine-owned array (struct Win)
+    const Win r_rem{r_win, P.off_rem}, r_de{r_win, P.off_de};
     const rsrc_t r_act = row_rsrc(io.actions, (!DBG || io.actions) ? N * n * 4u : 0u);
-    const rsrc_t r_scal = row_rsrc(P.scal, N * 32u);
-    const rsrc_t r_acc = row_rsrc(P.acc, N * 24u);
+    const Win r_scal{r_win, P.off_scal}, r_acc{r_win, P.off_acc};
     const rsrc_t r_obs = row_rsrc(io.out.obs, N * F * 4u);
-    const rsrc_t r_moer = row_rsrc(P.moer_obs, (unsigned)P.moer_days * EVC_MOER_ROWS * EVC_MOER_COLS * 4u);
-    const rsrc_t r_hist = row_rsrc(P.moer_hist, (unsigned)P.moer_days * EVC_MOER_ROWS * 8u);
-    const rsrc_t r_ts = row_rsrc(P.tables->timestep, EVC_MOER_ROWS * 4u);
+    const Win r_moer{r_win, P.off_moer}, r_hist{r_win, P.off_hist}, r_ts{r_win, P.off_ts};
     const rsrc_t r_rew = row_rsrc(io.out.reward, N * 8u);
     const rsrc_t r_term = row_rsrc(io.out.terminated, N);
     const rsrc_t r_bd = row_rsrc(io.out.breakdown, io.out.breakdown ? N * 24u : 0u);
-    const rsrc_t r_sess = row_rsrc(P.sessions, (unsigned)P.bank_slots * (unsigned)P.max_sessions * 8u);
-    const rsrc_t r_req = row_rsrc(P.requested, (unsigned)P.bank_slots * (unsigned)P.max_sessions * 8u);
+    const Win r_sess{r_win, P.off_sess}, r_req{r_win, P.off_req};
 
     auto station_mulw = [&](unsigned st, unsigned (&mw)[WORDS]) {
         const uint4 lo = st_mulw[st];
@@ -134,8 +130,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         const bool ev_ = quad_ < walk.hi && env_ < N;
         const unsigned eb_ = env_ * n;
         const unsigned soff = ev_ ? env_ * 32u : kOob;
-        L.s0 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 0, 0);
-        L.s1 = __builtin_amdgcn_raw_buffer_load_b128(r_scal, (int)soff, 16, 0);
+        L.s0 = buf_ld_v4(r_scal, soff);
+        L.s1 = buf_ld_v4(r_scal, soff == kOob ? kOob : soff + 16u);
         // entry slot 0 unconditionally: its extent is known only after the scalars arrive, and a
         // dependent load would cost a second round trip
         L.meta0 = buf_ld_u32(r_de, ev_ ? (eb_ + q) * 4u : kOob);
@@ -360,7 +356,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         bool pending = live && next_arrival <= t1 && cursor < n_sessions;
         while (__ballot(pending) != 0ull) {
             const unsigned sidx = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
-            const v2u sv = __builtin_amdgcn_raw_buffer_load_b64(r_sess, pending ? (int)(sidx * 8u) : (int)kOob, 0, 0);
+            const v2u sv = buf_ld_v2(r_sess, pending ? sidx * 8u : kOob);
             const double rq = buf_ld_f64(r_req, pending ? sidx * 8u : kOob);
             const int s_dep = (int)(short)(sv.x >> 16);
             const int s_est = (int)(short)(sv.y & 0xffffu);
@@ -525,8 +521,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             o1.z = ((unsigned)status & (unsigned)kStatusMask) | ((live ? count : A) << kCountShift);
             o1.w = (unsigned)episodes;
             const unsigned so = ((live || after_done) && q == 0u) ? env * 32u : kOob;
-            __builtin_amdgcn_raw_buffer_store_b128(o0, r_scal, (int)so, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(o1, r_scal, (int)so, 16, 0);
+            buf_st_v4(r_scal, so, o0);
+            buf_st_v4(r_scal, so == kOob ? kOob : so + 16u, o1);
         }
         };
         if (__builtin_expect(more, 0)) {

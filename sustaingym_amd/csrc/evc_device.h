@@ -112,6 +112,11 @@ struct Params {
     const double* moer_hist;       // [moer_days][289]        column 0 in float64 (reward)
     const float* moer_obs;         // [moer_days][289][37]    float32 (observation)
     const NetTables* tables;
+    // window over the engine-owned arrays the compact streaming kernel reads (struct Win): base, span and
+    // the byte offset of every array; win_span = 0 if they do not fit one 2 GiB window
+    const char* win_base;
+    unsigned win_span;
+    unsigned off_rem, off_de, off_scal, off_acc, off_sess, off_req, off_hist, off_moer, off_ts;
     // slow-path queue (environments whose projection needs the iterative solver)
     int* slow_count;               // counter this step appends to
     int* slow_count_next;          // counter the slow kernel clears for the next step
@@ -167,6 +172,43 @@ __device__ __forceinline__ void buf_st_i4(rsrc_t r, unsigned off, int4 x) {
     v4u v;
     v.x = (unsigned)x.x; v.y = (unsigned)x.y; v.z = (unsigned)x.z; v.w = (unsigned)x.w;
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0);
+}
+
+// Several arrays behind ONE buffer descriptor: `r` spans the window [base, base + span) that contains
+// them all, `off` (an SGPR) is the array's byte offset inside it and travels in the instruction's scalar
+// offset.  One descriptor + one SGPR per array instead of four SGPRs per array: the streaming kernels
+// otherwise spill dozens of descriptor words (v_readlane reloads on every use).  The hardware range
+// check is on voffset + soffset without 32-bit wrap (tools/scratch/soffset_probe.hip), so the
+// out-of-range voffset trick still drops the access.
+struct Win {
+    rsrc_t r;
+    unsigned off;
+};
+__device__ __forceinline__ double buf_ld_f64(Win w, unsigned off) {
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(w.r, (int)off, (int)w.off, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ v2u buf_ld_v2(Win w, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(w.r, (int)off, (int)w.off, 0);
+}
+__device__ __forceinline__ v4u buf_ld_v4(Win w, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(w.r, (int)off, (int)w.off, 0);
+}
+__device__ __forceinline__ unsigned buf_ld_u32(Win w, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(w.r, (int)off, (int)w.off, 0);
+}
+__device__ __forceinline__ float buf_ld_f32(Win w, unsigned off) { return __uint_as_float(buf_ld_u32(w, off)); }
+__device__ __forceinline__ void buf_st_f64(Win w, unsigned off, double x) {
+    v2u v;
+    v.x = (unsigned)__double2loint(x);
+    v.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(v, w.r, (int)off, (int)w.off, 0);
+}
+__device__ __forceinline__ void buf_st_u32(Win w, unsigned off, unsigned x) {
+    __builtin_amdgcn_raw_buffer_store_b32(x, w.r, (int)off, (int)w.off, 0);
+}
+__device__ __forceinline__ void buf_st_v4(Win w, unsigned off, v4u x) {
+    __builtin_amdgcn_raw_buffer_store_b128(x, w.r, (int)off, (int)w.off, 0);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -3,10 +3,12 @@
 // gfx950 kernels of evc_kernels.h / evc_solver.h.  There is no CPU execution path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -52,6 +54,7 @@ struct evc_engine {
     Params P{};
     uint32_t flags = 0;
     // owned device buffers
+    char* d_arena = nullptr;      // one block behind the pointers down to d_tables (struct Win window)
     double* d_rem = nullptr;
     int* d_depest = nullptr;
     int4* d_scal = nullptr;
@@ -101,8 +104,8 @@ int bind(evc_engine* e) {
 }
 
 void free_all(evc_engine* e) {
-    void* ptrs[] = {e->d_rem, e->d_depest, e->d_scal, e->d_acc, e->d_sessions, e->d_requested,
-                    e->d_nsess, e->d_slot_moer, e->d_moer_hist, e->d_moer_obs, e->d_tables,
+    void* ptrs[] = {e->d_arena /* rem, depest, scal, acc, sessions, requested, moer tables, net tables */,
+                    e->d_nsess, e->d_slot_moer,
                     e->d_slow_count, e->d_slow_list, e->d_idbuf, e->d_metrics, e->d_act, e->d_act_f32, e->d_obs,
                     e->d_reward, e->d_term, e->d_breakdown, e->d_final, e->d_pilots, e->d_rates,
                     e->d_proj, e->d_maxprofit, e->d_gen};
@@ -229,7 +232,8 @@ void compute_grids(evc_engine* e) {
     const bool fits32 = (double)e->P.N * e->P.F * 4.0 < 2.0e9 && (double)e->P.N * e->P.n * 8.0 < 2.0e9 &&
                         (double)e->P.bank_slots * e->P.max_sessions * 8.0 < 2.0e9 &&
                         (double)e->P.moer_days * EVC_MOER_ROWS * EVC_MOER_COLS * 4.0 < 2.0e9;
-    e->use_quad = e->P.m <= 16 && fits32 && !(kk && strcmp(kk, "wave") == 0);
+    // the compact streaming kernel additionally needs its arrays inside one 2 GiB window
+    e->use_quad = e->P.m <= 16 && fits32 && !(kk && strcmp(kk, "wave") == 0) && !(e->compact && e->P.win_span == 0u);
 }
 
 int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bins,
@@ -408,18 +412,30 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     const size_t N = P.N, n = P.n;
     hipError_t err = hipSuccess;
     auto A = [&](hipError_t x) { if (err == hipSuccess) err = x; };
-    A(dmalloc(&e->d_rem, N * n));
-    A(dmalloc(&e->d_depest, N * n));
-    A(dmalloc(&e->d_scal, N * 2));
-    A(dmalloc(&e->d_acc, N * 3));
-    A(dmalloc(&e->d_sessions, (size_t)bank_slots * max_sessions));
-    A(dmalloc(&e->d_requested, (size_t)bank_slots * max_sessions));
+    // The arrays the compact streaming kernel addresses through ONE buffer descriptor (struct Win) come
+    // out of one allocation, so that they always lie inside one window (256-byte aligned pieces).
+    {
+        size_t total = 0;
+        auto piece = [&](size_t bytes) { const size_t at = total; total += (bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_rem = piece(sizeof(double) * N * n), o_de = piece(sizeof(int) * N * n);
+        const size_t o_scal = piece(sizeof(int4) * N * 2), o_acc = piece(sizeof(double) * N * 3);
+        const size_t o_sess = piece(sizeof(evc_session) * (size_t)bank_slots * max_sessions);
+        const size_t o_req = piece(sizeof(double) * (size_t)bank_slots * max_sessions);
+        const size_t o_hist = piece(sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS);
+        const size_t o_moer = piece(sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS);
+        const size_t o_tab = piece(sizeof(NetTables));
+        A(hipMalloc((void**)&e->d_arena, total));
+        if (err == hipSuccess) {
+            char* b = e->d_arena;
+            e->d_rem = (double*)(b + o_rem); e->d_depest = (int*)(b + o_de); e->d_scal = (int4*)(b + o_scal);
+            e->d_acc = (double*)(b + o_acc); e->d_sessions = (evc_session*)(b + o_sess);
+            e->d_requested = (double*)(b + o_req); e->d_moer_hist = (double*)(b + o_hist);
+            e->d_moer_obs = (float*)(b + o_moer); e->d_tables = (NetTables*)(b + o_tab);
+        }
+    }
     A(dmalloc(&e->d_nsess, (size_t)bank_slots));
     A(dmalloc(&e->d_slot_moer, (size_t)bank_slots));
     A(dmalloc(&e->d_maxprofit, (size_t)bank_slots));
-    A(dmalloc(&e->d_moer_hist, (size_t)moer_days * EVC_MOER_ROWS));
-    A(dmalloc(&e->d_moer_obs, (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
-    A(dmalloc(&e->d_tables, 1));
     A(dmalloc(&e->d_slow_count, 2));
     A(dmalloc(&e->d_slow_list, N));
     A(dmalloc(&e->d_idbuf, 2 * N));
@@ -461,6 +477,26 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     P.sessions = e->d_sessions; P.requested = e->d_requested; P.n_sessions = e->d_nsess;
     P.slot_moer_day = e->d_slot_moer; P.moer_hist = e->d_moer_hist; P.moer_obs = e->d_moer_obs;
     P.tables = e->d_tables; P.slow_count = e->d_slow_count; P.slow_list = e->d_slow_list;
+    {   // window over the arrays the compact streaming kernel reads through one descriptor (struct Win)
+        struct Arr { const void* p; size_t bytes; unsigned* off; };
+        Params& Q = e->P;
+        const Arr arrs[] = {
+            {Q.rem, sizeof(double) * N * n, &Q.off_rem}, {Q.depest, sizeof(int) * N * n, &Q.off_de},
+            {Q.scal, sizeof(int4) * N * 2, &Q.off_scal}, {Q.acc, sizeof(double) * N * 3, &Q.off_acc},
+            {Q.sessions, sizeof(evc_session) * (size_t)bank_slots * max_sessions, &Q.off_sess},
+            {Q.requested, sizeof(double) * (size_t)bank_slots * max_sessions, &Q.off_req},
+            {Q.moer_hist, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS, &Q.off_hist},
+            {Q.moer_obs, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS, &Q.off_moer},
+            {e->d_tables->timestep, sizeof(float) * EVC_MOER_ROWS, &Q.off_ts}};
+        uintptr_t lo = UINTPTR_MAX, hi = 0;
+        for (const Arr& a : arrs) {
+            lo = std::min(lo, (uintptr_t)a.p);
+            hi = std::max(hi, (uintptr_t)a.p + a.bytes);
+        }
+        Q.win_base = (const char*)lo;
+        Q.win_span = (hi - lo) < 0x7fff0000ull ? (unsigned)(hi - lo) : 0u;
+        for (const Arr& a : arrs) *a.off = (unsigned)((uintptr_t)a.p - lo);
+    }
     compute_grids(e);
     *out = e;
     return EVC_OK;
