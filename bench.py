@@ -56,7 +56,9 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-envs', type=int, default=2048)
     p.add_argument('--cpu-steps', type=int, default=96)
-    p.add_argument('--kernel-timing-steps', type=int, default=64)
+    p.add_argument('--kernel-timing-steps', type=int, default=288,
+                   help='steps timed kernel by kernel for the roofline leg (288 = one whole day: the launch\n'
+                        'duration follows the time of day)')
     return p.parse_args()
 
 
@@ -140,7 +142,8 @@ def main():
         step(ptrs[i % len(ptrs)])
     _, total = all_gather_metrics(metrics_vector(eng.read_metrics()), coll_dev)
 
-    # ---- per-kernel duration with HIP events on the engine's stream (rank 0) ----
+    # ---- per-kernel duration with HIP events on the engine's stream (rank 0): start / stop events
+    # attached to each launch (evc_enable_timing), averaged over a whole day of steps ----
     roofline = None
     if rank == 0:
         eng.enable_timing(True)
@@ -171,6 +174,8 @@ def main():
                     'achieved': round(achieved, 2),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
                     'traffic': traffic, 'state_layout': layout, 'avg_kernel_ms': round(avg_main, 5),
+                    'kernel_ms_min_max': [round(float(np.min(main_ms)), 5), round(float(np.max(main_ms)), 5)],
+                    'kernel_launches_timed': len(main_ms),
                     'traffic_gbs': (round(traffic / (avg_main * 1e-3) / 1e9, 2) if traffic else None),
                     'solver_kernel_ms': round(avg_slow, 5),
                     'slow_queue_envs_per_step': (round(float(np.mean(slow_cnt)), 1) if slow_cnt else 0.0),

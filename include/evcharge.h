@@ -267,12 +267,15 @@ int evc_clear_status(evc_engine* e);
  * status, 0, 0. */
 int evc_read_metrics(evc_engine* e, double* out_host);
 
-/* Duration (ms) of the most recent evc_step's kernels measured with HIP events on the
- * engine's stream (enabled by evc_enable_timing(e,1)); used by bench.py's roofline leg. */
 /* Number of environments the most recent evc_step handed to the iterative/exact projection kernel
  * (diagnostic; synchronises the stream). */
 int evc_last_slow_count(evc_engine* e, int32_t* count);
 
+/* Duration (ms) of the most recent evc_step's kernels: with evc_enable_timing(e,1) the streaming kernel
+ * and the slow kernel are launched with their own start / stop HIP events on the engine's stream
+ * (hipExtLaunchKernel), so the figures are the kernels' begin-to-end times, as a kernel trace reports
+ * them; evc_last_step_ms waits for the step.  Used by bench.py's roofline leg.  ms_slow = 0 when the
+ * step launched no slow kernel (projection off). */
 int evc_enable_timing(evc_engine* e, int32_t on);
 int evc_last_step_ms(evc_engine* e, float* ms_main, float* ms_slow);
 

@@ -2,6 +2,7 @@
 // EV-charging step engine.  Host-side bookkeeping only; all simulation arithmetic is in the
 // gfx950 kernels of evc_kernels.h / evc_solver.h.  There is no CPU execution path.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -85,7 +86,7 @@ struct evc_engine {
     double* d_proj = nullptr;
     // timing
     bool timing = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // main start/stop, slow start/stop
     bool ev_valid = false, ev_slow = false;
     // host mirrors
     unsigned long long env_steps = 0;
@@ -265,70 +266,64 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     e->P.slow_count = e->d_slow_count + (e->step_parity & 1);
     e->P.slow_count_next = e->d_slow_count + ((e->step_parity + 1) & 1);
     e->step_parity ^= 1;
-    if (e->timing) HIP_TRY(hipEventRecord(e->ev[0], e->stream));
     const int words = (e->P.G + 1) / 2;
     const bool dbg = out->pilots || out->rates || out->projected || out->returns ||
                      action_kind == EVC_ACTION_GREEDY;
 #ifndef EVC_ABL_NO_SOLVER
 #define EVC_ABL_NO_SOLVER 0   /* ablation builds only (tools/build_variant.sh): timing without the slow kernel */
 #endif
-#define EVC_LAUNCH_QUAD_(KQ, W)                                                                         \
+    // With timing on, the two kernels carry their own start / stop events (hipExtLaunchKernel: the
+    // events read the dispatch packet's begin / end timestamps, i.e. the duration a kernel trace
+    // reports, without the gaps between stream operations).
+    auto launch = [&](auto kernel, int grid, int block, int which) {
+        if (e->timing)
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, e->stream, e->ev[2 * which],
+                                  e->ev[2 * which + 1], 0, e->P, io);
+        else
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, e->stream, e->P, io);
+    };
+    bool solver_ran = false;
+#define EVC_LAUNCH_(KDBG, KFAST, KPLAIN, GRID, W)                                                   \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \
-            if (dbg) hipLaunchKernelGGL((KQ<true, W, true>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
-            else hipLaunchKernelGGL((KQ<true, W, false>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
-            if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
-            if (!EVC_ABL_NO_SOLVER)                                                                \
-            hipLaunchKernelGGL((solver_step_kernel<W>), dim3(e->solver_grid), dim3(64), 0,         \
-                               e->stream, e->P, io);                                               \
+            if (dbg) launch(KDBG, GRID, 256, 0);                                                   \
+            else launch(KFAST, GRID, 256, 0);                                                      \
+            if (!EVC_ABL_NO_SOLVER) {                                                              \
+                launch(solver_step_kernel<W>, e->solver_grid, 64, 1);                              \
+                solver_ran = true;                                                                 \
+            }                                                                                      \
         } else {                                                                                   \
-            if (dbg) hipLaunchKernelGGL((KQ<false, W, true>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
-            else hipLaunchKernelGGL((KQ<false, W, false>), dim3(e->quad_grid), dim3(256), 0, e->stream, e->P, io); \
-            if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
+            launch(KPLAIN, GRID, 256, 0);                                                          \
         }                                                                                          \
         break;
-#define EVC_LAUNCH_QUAD(W) EVC_LAUNCH_QUAD_(step_kernel_quad, W)
-#define EVC_LAUNCH_CQUAD(W) EVC_LAUNCH_QUAD_(step_kernel_cquad, W)
-    if (e->use_quad && e->compact) {
-        switch (words) {
-            EVC_LAUNCH_CQUAD(1) EVC_LAUNCH_CQUAD(2) EVC_LAUNCH_CQUAD(3) EVC_LAUNCH_CQUAD(4)
-            EVC_LAUNCH_CQUAD(5) EVC_LAUNCH_CQUAD(6) EVC_LAUNCH_CQUAD(7) EVC_LAUNCH_CQUAD(8)
-            default: return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
-        }
-    } else if (e->use_quad) {
-        switch (words) {
-            EVC_LAUNCH_QUAD(1) EVC_LAUNCH_QUAD(2) EVC_LAUNCH_QUAD(3) EVC_LAUNCH_QUAD(4)
-            EVC_LAUNCH_QUAD(5) EVC_LAUNCH_QUAD(6) EVC_LAUNCH_QUAD(7) EVC_LAUNCH_QUAD(8)
-            default: return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
-        }
-    } else
-#undef EVC_LAUNCH_QUAD
-#undef EVC_LAUNCH_CQUAD
-#undef EVC_LAUNCH_QUAD_
-#define EVC_LAUNCH(W)                                                                              \
-    case W:                                                                                        \
-        if (e->P.project) {                                                                        \
-            hipLaunchKernelGGL((step_kernel<true, W>), dim3(e->step_grid), dim3(256), 0, e->stream, \
-                               e->P, io);                                                          \
-            if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
-            hipLaunchKernelGGL((solver_step_kernel<W>), dim3(e->solver_grid), dim3(64), 0,         \
-                               e->stream, e->P, io);                                               \
-        } else {                                                                                   \
-            hipLaunchKernelGGL((step_kernel<false, W>), dim3(e->step_grid), dim3(256), 0,          \
-                               e->stream, e->P, io);                                               \
-            if (e->timing) HIP_TRY(hipEventRecord(e->ev[1], e->stream));                          \
-        }                                                                                          \
-        break;
-    switch (words) {
-        EVC_LAUNCH(1) EVC_LAUNCH(2) EVC_LAUNCH(3) EVC_LAUNCH(4)
-        EVC_LAUNCH(5) EVC_LAUNCH(6) EVC_LAUNCH(7) EVC_LAUNCH(8)
-        default: return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
+#define EVC_LAUNCH_QUAD(W)                                                                          \
+    EVC_LAUNCH_((step_kernel_quad<true, W, true>), (step_kernel_quad<true, W, false>),             \
+                (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, W)
+#define EVC_LAUNCH_CQUAD(W)                                                                         \
+    EVC_LAUNCH_((step_kernel_cquad<true, W, true>), (step_kernel_cquad<true, W, false>),           \
+                (dbg ? step_kernel_cquad<false, W, true> : step_kernel_cquad<false, W, false>), e->quad_grid, W)
+#define EVC_LAUNCH_WAVE(W)                                                                          \
+    EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, W)
+#define EVC_LAUNCH_ALL(L)                                                                           \
+    switch (words) {                                                                               \
+        L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8)                                                    \
+        default: return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);                    \
     }
-#undef EVC_LAUNCH
+    if (e->use_quad && e->compact) {
+        EVC_LAUNCH_ALL(EVC_LAUNCH_CQUAD)
+    } else if (e->use_quad) {
+        EVC_LAUNCH_ALL(EVC_LAUNCH_QUAD)
+    } else {
+        EVC_LAUNCH_ALL(EVC_LAUNCH_WAVE)
+    }
+#undef EVC_LAUNCH_ALL
+#undef EVC_LAUNCH_WAVE
+#undef EVC_LAUNCH_CQUAD
+#undef EVC_LAUNCH_QUAD
+#undef EVC_LAUNCH_
     if (e->timing) {
-        HIP_TRY(hipEventRecord(e->ev[2], e->stream));
         e->ev_valid = true;
-        e->ev_slow = e->P.project != 0;
+        e->ev_slow = solver_ran;
     }
     HIP_TRY(hipGetLastError());
     e->env_steps += (unsigned long long)e->P.N;
@@ -974,10 +969,10 @@ int evc_last_step_ms(evc_engine* e, float* ms_main, float* ms_slow) {
     if (!e) return fail(EVC_EINVAL, "null engine");
     if (!e->ev_valid) return fail(EVC_ESTATE, "evc_last_step_ms: no timed step recorded");
     if (int rc = bind(e)) return rc;
-    HIP_TRY(hipEventSynchronize(e->ev[2]));
+    HIP_TRY(hipEventSynchronize(e->ev_slow ? e->ev[3] : e->ev[1]));
     float a = 0.f, b = 0.f;
     HIP_TRY(hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+    if (e->ev_slow) HIP_TRY(hipEventElapsedTime(&b, e->ev[2], e->ev[3]));
     if (ms_main) *ms_main = a;
     if (ms_slow) *ms_slow = e->ev_slow ? b : 0.f;
     return EVC_OK;

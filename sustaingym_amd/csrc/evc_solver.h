@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
     ln.gid = lnet.gid;
 
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
-        long long c0 = SOLVER_CLK();
+        [[maybe_unused]] long long c0 = SOLVER_CLK();
         const int env = rfl(P.slow_list[q]);
         const EnvLoads cur = issue_loads(P, io, env, lane);
         EnvRegs r;
@@ -275,13 +275,13 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
                 }
             }
         }
-        long long c1 = SOLVER_CLK();
+        [[maybe_unused]] long long c1 = SOLVER_CLK();
         SOLVER_STAT(8, c1 - c0);
-        long long t_build = 0, t_chol = 0, t_ls = 0, t_head = 0;
+        [[maybe_unused]] long long t_build = 0, t_chol = 0, t_ls = 0, t_head = 0;
         SOLVER_STAT(0, 1);
         SOLVER_STAT(1, settled ? 1 : 0);
         if (!settled) solver_pass(P, L, ln, lane, L.z);
-        int n_iter = 0, n_trial = 0, n_act = 0;
+        [[maybe_unused]] int n_iter = 0, n_trial = 0, n_act = 0;
 
         double mu = 1e-3;
         bool converged = settled, last_ok = false;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
             if (!state_current) solver_pass(P, L, ln, lane, L.z);
             t_ls += SOLVER_CLK() - cd;
         }
-        long long c2 = SOLVER_CLK();
+        [[maybe_unused]] long long c2 = SOLVER_CLK();
         SOLVER_STAT(9, c2 - c1); SOLVER_STAT(10, t_head); SOLVER_STAT(11, t_build); SOLVER_STAT(12, t_chol); SOLVER_STAT(13, t_ls);
         SOLVER_STAT(2, n_iter); SOLVER_STAT(3, n_trial); SOLVER_STAT(4, n_act); SOLVER_STAT(5, n_iter >= 20 ? 1 : 0);
         SOLVER_STAT(6, n_act == 1 ? 1 : 0); SOLVER_STAT(7, (!converged && !last_ok) ? 1 : 0);
