@@ -198,10 +198,18 @@ def main():
         for i in range(cs):
             bat.step(acts[i % len(acts)], autoreset=True, debug=False)
         dt = time.perf_counter() - t1
+        # the same sample continued on one thread (SURVEY §8d asks for both), bounded to a few seconds
+        c1 = max(1, cs // 4)
+        t1 = time.perf_counter()
+        for i in range(c1):
+            bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=1)
+        dt1 = time.perf_counter() - t1
         cpu_baseline = {'value': round(cn * cs / dt, 1), 'unit': 'env-steps/s', 'cores': cores,
                         'kind': 'port',
                         'sample': f'{cn} envs x {cs} steps (periods 97..{96 + cs}) of the same workload, '
-                                  f'oracle/ C restatement, OpenMP over envs'}
+                                  f'oracle/ C restatement, OpenMP over envs',
+                        'single_thread_value': round(cn * c1 / dt1, 1),
+                        'single_thread_sample': f'{cn} envs x {c1} steps (periods {97 + cs}..{96 + cs + c1}), 1 thread'}
 
     # Reset-path row, reported beside the headline: refill the whole episode bank with
     # the on-device GMM generator (after the timed region; the bank is not used again).

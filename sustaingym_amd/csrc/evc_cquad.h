@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
     const rsrc_t r_act = row_rsrc(io.actions, (!DBG || io.actions) ? N * n * 4u : 0u);
     const Win r_scal{r_win, P.off_scal}, r_acc{r_win, P.off_acc};
     const rsrc_t r_obs = row_rsrc(io.out.obs, N * F * 4u);
-    const Win r_moer{r_win, P.off_moer}, r_hist{r_win, P.off_hist}, r_ts{r_win, P.off_ts};
+    const Win r_moer{r_win, P.off_moer}, r_hist{r_win, P.off_hist};
     const rsrc_t r_rew = row_rsrc(io.out.reward, N * 8u);
     const rsrc_t r_term = row_rsrc(io.out.terminated, N);
     const rsrc_t r_bd = row_rsrc(io.out.breakdown, io.out.breakdown ? N * 24u : 0u);
@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         const unsigned env = (unsigned)quad * 4u + row;
         const bool ev = env < N;
         const unsigned ebase = env * n;
+        const unsigned obase = env * F;                     // observation row
         const QuadRaw cur = nxt;
         nxt = issue(quad + walk.stride);
 
@@ -165,8 +166,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
 #pragma unroll
             for (int j = 0; j < kSlots; j++) {
                 const float a = cur.a[j];
-                clamped = clamped || !(a >= 0.0f && a <= 1.0f);          // also true for NaN
                 a_st[j] = fminf(fmaxf(a, 0.0f), 1.0f);                    // NaN -> 0
+                clamped = clamped || (a_st[j] != a);                      // also true for NaN
                 act_row[j * 16 + q] = a_st[j];
             }
         }
@@ -205,8 +206,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         for (int p = 0; p < 3; p++) {
             const unsigned idx = (unsigned)p * 16u + q;                 // position in [forecast | prev | ts]
             const unsigned col = idx < k ? idx + 1u : 0u;
-            mo[p] = buf_ld_f32(r_moer, (live && idx <= k) ? (mrow * EVC_MOER_COLS + col) * 4u : kOob);
-            if (idx == k + 1u) mo[p] = buf_ld_f32(r_ts, live ? (unsigned)t1 * 4u : kOob);
+            // one load per lane: MOER columns and the timestep table live in the same window
+            const unsigned o_moer = P.off_moer + (mrow * EVC_MOER_COLS + col) * 4u;
+            const unsigned o_ts = P.off_ts + (unsigned)t1 * 4u;
+            const unsigned o = idx <= k ? o_moer : o_ts;
+            mo[p] = buf_ld_f32(r_win, (live && idx <= k + 1u) ? o : kOob);
         }
 
         // ---- entries: decode, action, y (box clip of the projection), class sums ----
@@ -463,14 +467,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
                 const rsrc_t r_fin = row_rsrc(io.out.final_obs, N * F * 4u);
 #pragma unroll
                 for (int j = 0; j < kSlots; j++) {
-                    const unsigned o = (do_reset && st_valid[j]) ? (env * F + (unsigned)j * 16u + q) * 4u : kOob;
+                    const unsigned o = (do_reset && st_valid[j]) ? (obase + (unsigned)j * 16u + q) * 4u : kOob;
                     buf_st_f32(r_fin, o, d[j].x);
                     buf_st_f32(r_fin, o == kOob ? kOob : o + n * 4u, d[j].y);
                 }
 #pragma unroll
                 for (int p = 0; p < 3; p++) {
                     const unsigned idx = (unsigned)p * 16u + q;
-                    buf_st_f32(r_fin, (do_reset && idx < k + 2u) ? (env * F + 2u * n + idx) * 4u : kOob, mo[p]);
+                    buf_st_f32(r_fin, (do_reset && idx < k + 2u) ? (obase + 2u * n + idx) * 4u : kOob, mo[p]);
                 }
             }
             if (do_reset) {
@@ -497,14 +501,15 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         // ---- observation (env.py:381-394) + state write-back ----
 #pragma unroll
         for (int j = 0; j < kSlots; j++) {
-            const unsigned o = (live && st_valid[j]) ? (env * F + (unsigned)j * 16u + q) * 4u : kOob;
-            buf_st_f32(r_obs, o, d[j].x);
-            buf_st_f32(r_obs, o == kOob ? kOob : o + n * 4u, d[j].y);
+            const bool w = live && st_valid[j];
+            const unsigned o = (obase + (unsigned)j * 16u + q) * 4u;
+            buf_st_f32(r_obs, w ? o : kOob, d[j].x);
+            buf_st_f32(r_obs, w ? o + n * 4u : kOob, d[j].y);
         }
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             const unsigned idx = (unsigned)p * 16u + q;
-            buf_st_f32(r_obs, (live && idx < k + 2u) ? (env * F + 2u * n + idx) * 4u : kOob, mo[p]);
+            buf_st_f32(r_obs, (live && idx < k + 2u) ? (obase + 2u * n + idx) * 4u : kOob, mo[p]);
         }
         auto store_entry = [&](int c) {
             const bool w = live && alive[c] && !do_reset;

@@ -35,10 +35,12 @@ __device__ __forceinline__ unsigned row_allreduce_u32(unsigned v) {
     return v;
 }
 __device__ __forceinline__ double row_allreduce_f64(double v) {
-    v += dpp_f64<0x121, 0xf, false>(v);
-    v += dpp_f64<0x122, 0xf, false>(v);
-    v += dpp_f64<0x124, 0xf, false>(v);
-    v += dpp_f64<0x128, 0xf, false>(v);
+    // a rotation has no invalid source lane; bound_ctrl only tells the compiler that the destination's
+    // previous contents are dead (no v_mov 0 per half)
+    v += dpp_f64<0x121, 0xf, true>(v);
+    v += dpp_f64<0x122, 0xf, true>(v);
+    v += dpp_f64<0x124, 0xf, true>(v);
+    v += dpp_f64<0x128, 0xf, true>(v);
     return v;
 }
 // does any lane of MY row have `flag` set?
