@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             }
         }
 
-        // ---- pilots (env.py:366-378), battery charge, class sums of the pilots ----
+        // ---- pilots (env.py:366-378), battery charge ----
         double pilot[kSlots], amps[kSlots];
 #pragma unroll
         for (int c = 0; c < kSlots; c++) { pilot[c] = 0.0; amps[c] = 0.0; }
@@ -297,13 +297,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             const unsigned info = st_info[st[c]];
             const double pl = legal_pilot(y[c], (info >> 7) != 0u);     // y = 0 on invalid entries
             pilot[c] = pl;
-            if (!station_pilots) {
-                const unsigned qp = (unsigned)(int)pl;                   // <= 32
-                unsigned mw[WORDS];
-                station_mulw(st[c], mw);
-#pragma unroll
-                for (int w = 0; w < WORDS; w++) pwords[w] = __umul24(qp, mw[w]) + pwords[w];
-            }
             amps[c] = charge_ev(pl, rem[c]);                             // every entry is a plugged-in EV
             if (live && valid[c]) obs_row[st[c]].amps = amps[c];
         };
@@ -325,11 +318,22 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             }
         }
 
-        // ---- reductions inside the row ----
-#pragma unroll
-        for (int w = 0; w < WORDS; w++) pwords[w] = row_allreduce_u32(pwords[w]);
+        // ---- constraint excess of the pilots (env.py:449-452) ----
+        // With the projection the y-screen above usually proves the pilots feasible as well
+        // (pilots_screened); their class sums are only formed for wavefronts where some row is open.
         double excess = 0.0;
-        {
+        if (station_pilots || __ballot(live && !pilots_screened) != 0ull) {
+            if (!station_pilots) {
+#pragma unroll
+                for (int c = 0; c < NS; c++) {
+                    unsigned mw[WORDS];
+                    station_mulw(st[c], mw);
+#pragma unroll
+                    for (int w = 0; w < WORDS; w++) pwords[w] = __umul24((unsigned)(int)pilot[c], mw[w]) + pwords[w];   // <= 32
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) pwords[w] = row_allreduce_u32(pwords[w]);
             bool maybe = false;
             if (q < m && !pilots_screened) maybe = !(quad_mag2_f32<WORDS>(net, q, pwords) < net.thr_p2[q]);
             if (__builtin_expect(__ballot(maybe && live) != 0ull, 0)) {   // rare: exact evaluation
