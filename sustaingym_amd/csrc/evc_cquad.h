@@ -50,31 +50,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
     const unsigned m = (unsigned)P.m, k = (unsigned)P.k;
     const unsigned N = (unsigned)P.N;
 
-    if (tid < 64u) {
-        const unsigned s = tid;
-        const bool valid = s < n;
-        int gid = 0;
-        for (int g = 0; g < P.G; g++)
-            if ((P.group_mask[g] >> s) & 1ull) gid = g;
-        unsigned mw[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) mw[w] = (valid && (gid >> 1) == w) ? ((gid & 1) ? 65536u : 1u) : 0u;
-        st_mulw[s] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-        st_mulw_hi[s] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
-        st_info[s] = (unsigned char)((unsigned)gid | ((unsigned)((P.cc_mask >> s) & 1ull) << 7));
-    }
-#pragma unroll
-    for (int j = 0; j < kSlots; j++) {
-        obs_img[wv][row][j * 16 + q] = StationCell{0.0f, 0.0f, 0.0};
-        act_img[wv][row][j * 16 + q] = 0.0f;
-        if (DBG) dbg_img[wv][row][j * 16 + q] = 0.0;
-    }
-    stage_net(net, P);                              // ends with the workgroup barrier
-
-    StationCell* const obs_row = obs_img[wv][row];
-    float* const act_row = act_img[wv][row];
-    double* const dbg_row = dbg_img[DBG ? wv : 0][row];
-
     // dense side: station j*16+q of the row (action range check, observation stores)
     bool st_valid[kSlots];
 #pragma unroll
@@ -90,27 +65,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
     const rsrc_t r_term = row_rsrc(io.out.terminated, N);
     const rsrc_t r_bd = row_rsrc(io.out.breakdown, io.out.breakdown ? N * 24u : 0u);
     const Win r_sess{r_win, P.off_sess}, r_req{r_win, P.off_req};
-
-    auto station_mulw = [&](unsigned st, unsigned (&mw)[WORDS]) {
-        const uint4 lo = st_mulw[st];
-        const unsigned all[4] = {lo.x, lo.y, lo.z, lo.w};
-#pragma unroll
-        for (int w = 0; w < WORDS && w < 4; w++) mw[w] = all[w];
-        if (WORDS > 4) {
-            const uint4 hi = st_mulw_hi[st];
-            const unsigned allh[4] = {hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-            for (int w = 4; w < WORDS; w++) mw[w] = allh[w - 4];
-        }
-    };
-    // Cross-lane LDS hand-off inside the wave.  The LDS pipeline executes a wave's ds instructions in
-    // issue order, so only the COMPILER must be kept from reordering them; a real fence would also
-    // drain every outstanding global load and store (s_waitcnt vmcnt(0)) several times per step.
-    auto lds_sync = [&]() {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-    };
 
     const bool greedy = DBG && io.action_kind == EVC_ACTION_GREEDY;
     const unsigned nquads = (N + 3u) >> 2;
@@ -142,7 +96,57 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         L.acc = buf_ld_f64(r_acc, (ev_ && q < 3u) ? env_ * 24u + q * 8u : kOob);
         return L;
     };
+    // The first quad's loads are issued before the LDS tables are built: the two latency chains (network
+    // tables from global memory, first state / action rows) overlap instead of following each other —
+    // a wave runs only four iterations at N = 65 536, so the prologue is a visible share of the launch.
     QuadRaw nxt = issue(walk.first);
+
+    if (tid < 64u) {
+        const unsigned s = tid;
+        const bool valid = s < n;
+        int gid = 0;
+        for (int g = 0; g < P.G; g++)
+            if ((P.group_mask[g] >> s) & 1ull) gid = g;
+        unsigned mw[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) mw[w] = (valid && (gid >> 1) == w) ? ((gid & 1) ? 65536u : 1u) : 0u;
+        st_mulw[s] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+        st_mulw_hi[s] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
+        st_info[s] = (unsigned char)((unsigned)gid | ((unsigned)((P.cc_mask >> s) & 1ull) << 7));
+    }
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        obs_img[wv][row][j * 16 + q] = StationCell{0.0f, 0.0f, 0.0};
+        act_img[wv][row][j * 16 + q] = 0.0f;
+        if (DBG) dbg_img[wv][row][j * 16 + q] = 0.0;
+    }
+    stage_net(net, P);                              // ends with the workgroup barrier
+
+    StationCell* const obs_row = obs_img[wv][row];
+    float* const act_row = act_img[wv][row];
+    double* const dbg_row = dbg_img[DBG ? wv : 0][row];
+
+    auto station_mulw = [&](unsigned st, unsigned (&mw)[WORDS]) {
+        const uint4 lo = st_mulw[st];
+        const unsigned all[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+        for (int w = 0; w < WORDS && w < 4; w++) mw[w] = all[w];
+        if (WORDS > 4) {
+            const uint4 hi = st_mulw_hi[st];
+            const unsigned allh[4] = {hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int w = 4; w < WORDS; w++) mw[w] = allh[w - 4];
+        }
+    };
+    // Cross-lane LDS hand-off inside the wave.  The LDS pipeline executes a wave's ds instructions in
+    // issue order, so only the COMPILER must be kept from reordering them; a real fence would also
+    // drain every outstanding global load and store (s_waitcnt vmcnt(0)) several times per step.
+    auto lds_sync = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    };
+
     for (int quad = walk.first; quad < walk.hi; quad += walk.stride) {
         const unsigned env = (unsigned)quad * 4u + row;
         const bool ev = env < N;
