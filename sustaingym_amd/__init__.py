@@ -32,4 +32,18 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
+def _register_with_gymnasium() -> None:
+    """sustaingym/__init__.py:1-7 registers 'sustaingym/EVCharging-v0'; with gymnasium installed the
+    same id (and 'sustaingym_amd/EVCharging-v0') resolves to this package's EVChargingEnv."""
+    try:
+        from gymnasium.envs.registration import register, registry
+    except Exception:       # gymnasium absent (this build image): nothing to register with
+        return
+    for env_id in ('sustaingym/EVCharging-v0', 'sustaingym_amd/EVCharging-v0'):
+        if env_id not in registry:
+            register(id=env_id, entry_point='sustaingym_amd.envs:EVChargingEnv', nondeterministic=False)
+
+
+_register_with_gymnasium()
+
 __version__ = '0.1.0'

@@ -26,12 +26,22 @@ from .event_generation import (AbstractTraceGenerator, BatchedGMMTraceGenerator,
                                EventTable, RealTraceBank)
 from .network import site_str_to_site
 
+# With gymnasium / pettingzoo installed the classes derive from the same bases as the reference's
+# (env.py:20 gymnasium.Env, wrappers.py:13 gymnasium.ActionWrapper, multiagent_env.py:18 ParallelEnv), so
+# isinstance checks of StableBaselines3 / RLLib's PettingZoo adapter hold; without them (this build
+# image) they are plain classes with the same protocol.
 try:  # pragma: no cover
     import gymnasium as _gym
     _EnvBase = _gym.Env
+    _ActionWrapperBase = _gym.ActionWrapper
 except Exception:
     _gym = None
     _EnvBase = object
+    _ActionWrapperBase = object
+try:  # pragma: no cover
+    from pettingzoo import ParallelEnv as _ParallelEnvBase
+except Exception:
+    _ParallelEnvBase = object
 
 MAX_SESSIONS = 256
 OBS_KEYS = ('demands', 'est_departures', 'forecasted_moer', 'prev_moer', 'timestep')  # sorted
@@ -186,13 +196,15 @@ class EVChargingEnv(_EnvBase):
         return None
 
 
-class DiscreteActionWrapper:
+class DiscreteActionWrapper(_ActionWrapperBase):
     """wrappers.py:13-45: discrete {0..bins-1}^n actions -> a/(bins-1).  The float32 division
     itself runs in the engine (EVC_ACTION_DISCRETE)."""
 
     def __init__(self, env: EVChargingEnv, bins: int = 5):
         if not isinstance(env.action_space, spaces.Box):
             raise ValueError('Should only be used to wrap continuous env')      # wrappers.py:28
+        if _ActionWrapperBase is not object:
+            super().__init__(env)
         self.env = env
         self._bins = bins
         dims = env.action_space.shape
@@ -204,6 +216,8 @@ class DiscreteActionWrapper:
         return repr(self.env)
 
     def __getattr__(self, name):
+        if name == 'env':                          # not constructed yet: no recursion
+            raise AttributeError(name)
         return getattr(self.env, name)
 
     def action(self, action):                                                    # wrappers.py:43-45
@@ -219,7 +233,7 @@ class DiscreteActionWrapper:
         return self.env.close()
 
 
-class MultiAgentEVChargingEnv:
+class MultiAgentEVChargingEnv(_ParallelEnvBase):
     """multiagent_env.py:18-218 (PettingZoo ``ParallelEnv`` protocol, one agent per EVSE).
 
     ``periods_delay`` > 0: the reference implementation stores aliases of reused buffers, so its
