@@ -42,6 +42,10 @@ try:  # pragma: no cover
     from pettingzoo import ParallelEnv as _ParallelEnvBase
 except Exception:
     _ParallelEnvBase = object
+try:  # pragma: no cover
+    from stable_baselines3.common.vec_env import VecEnv as _SB3VecEnvBase
+except Exception:
+    _SB3VecEnvBase = object
 
 MAX_SESSIONS = 256
 OBS_KEYS = ('demands', 'est_departures', 'forecasted_moer', 'prev_moer', 'timestep')  # sorted
@@ -659,13 +663,17 @@ class MultiAgentEVChargingVectorEnv:
         self.venv.close()
 
 
-class SB3VecEnv:
+class SB3VecEnv(_SB3VecEnvBase):
     """stable_baselines3 ``VecEnv`` protocol over :class:`EVChargingVectorEnv`
-    (used like train_stable_baselines.py:275 uses SubprocVecEnv; policy ``MultiInputPolicy``)."""
+    (used like train_stable_baselines.py:275 uses SubprocVecEnv; policy ``MultiInputPolicy``).
+    Derives from SB3's ``VecEnv`` when stable_baselines3 is installed, so that algorithms take it as
+    it is instead of wrapping it in a DummyVecEnv."""
 
     def __init__(self, venv: EVChargingVectorEnv):
         assert venv.output == 'numpy'
         self.venv = venv
+        if _SB3VecEnvBase is not object:       # sets num_envs / spaces, queries get_attr('render_mode')
+            super().__init__(venv.num_envs, venv.single_observation_space, venv.single_action_space)
         self.num_envs = venv.num_envs
         self.observation_space = venv.single_observation_space
         self.action_space = venv.single_action_space
@@ -707,7 +715,9 @@ class SB3VecEnv:
         self.venv.close()
 
     def get_attr(self, attr_name, indices=None):
-        idx = range(self.num_envs) if indices is None else indices
+        idx = range(self.venv.num_envs) if indices is None else indices
+        if attr_name == 'render_mode':
+            return [None for _ in idx]
         return [getattr(self.venv, attr_name) for _ in idx]
 
     def set_attr(self, attr_name, value, indices=None) -> None:

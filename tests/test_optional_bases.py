@@ -1,5 +1,5 @@
-"""With gymnasium / pettingzoo importable the public classes derive from the reference's bases
-(env.py:20, wrappers.py:13, multiagent_env.py:18) and the env id of sustaingym/__init__.py:3-7 is
+"""With gymnasium / pettingzoo / stable_baselines3 importable the public classes derive from the reference's bases
+(env.py:20, wrappers.py:13, multiagent_env.py:18; SB3VecEnv: stable_baselines3's VecEnv) and the env id of sustaingym/__init__.py:3-7 is
 registered.  Neither package exists in the build image, so the check runs in a subprocess against
 structural stand-ins of the two packages (just the class skeletons gymnasium 0.28 defines)."""
 import os
@@ -71,6 +71,17 @@ assert np.all(d.last == np.float32(0.25))
 assert w.marker == 'forwarded' and w.reset() == ('o', {})
 w.close()
 assert d.closed
+
+import stable_baselines3.common.vec_env as sb3
+assert issubclass(envs.SB3VecEnv, sb3.VecEnv)
+class DummyVenv:
+    output = 'numpy'
+    num_envs = 3
+    single_observation_space = 'single-obs'
+    single_action_space = 'single-act'
+v = envs.SB3VecEnv(DummyVenv())
+assert v.num_envs == 3 and v.observation_space == 'single-obs' and v.action_space == 'single-act'
+assert v.render_mode is None and v.base_init_ran
 print('OK')
 '''
 
@@ -85,6 +96,19 @@ def test_reference_bases_when_packages_exist(tmp_path):
         registry = {}
         def register(id, entry_point, **kwargs):
             registry[id] = entry_point
+    '''))
+    sb = tmp_path / 'stable_baselines3' / 'common'
+    sb.mkdir(parents=True)
+    (tmp_path / 'stable_baselines3' / '__init__.py').write_text('')
+    (sb / '__init__.py').write_text('')
+    (sb / 'vec_env.py').write_text(textwrap.dedent('''
+        class VecEnv:
+            def __init__(self, num_envs, observation_space, action_space):
+                self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
+                modes = self.get_attr('render_mode')          # as stable_baselines3 >= 2.0 does
+                assert len(modes) == num_envs
+                self.render_mode = modes[0]
+                self.base_init_ran = True
     '''))
     p = tmp_path / 'pettingzoo'
     p.mkdir()
