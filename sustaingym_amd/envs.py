@@ -39,6 +39,12 @@ except Exception:
     _EnvBase = object
     _ActionWrapperBase = object
 try:  # pragma: no cover
+    from gymnasium.vector import VectorEnv as _VectorEnvBase
+    from gymnasium.vector.utils import batch_space as _batch_space
+except Exception:
+    _VectorEnvBase = object
+    _batch_space = None
+try:  # pragma: no cover
     from pettingzoo import ParallelEnv as _ParallelEnvBase
 except Exception:
     _ParallelEnvBase = object
@@ -326,7 +332,7 @@ class MultiAgentEVChargingEnv(_ParallelEnvBase):
         return self.action_spaces[agent]
 
 
-class EVChargingVectorEnv:
+class EVChargingVectorEnv(_VectorEnvBase):
     """N independent EVChargingEnv instances stepped by one engine call (Gymnasium 0.28
     ``VectorEnv`` semantics: batched dict observation, autoreset, ``final_observation``).
 
@@ -378,8 +384,12 @@ class EVChargingVectorEnv:
         self.single_action_space = (spaces.MultiDiscrete(np.full(n, discrete_bins, np.int64))
                                     if discrete_bins > 0 else
                                     spaces.Box(low=0, high=1.0, shape=(n,), dtype=np.float32))
-        self.observation_space = self.single_observation_space
-        self.action_space = self.single_action_space
+        # gymnasium.vector.VectorEnv's attributes (its __init__ is not called: it would only set these)
+        self.observation_space = (_batch_space(self.single_observation_space, N) if _batch_space
+                                  else self.single_observation_space)
+        self.action_space = (_batch_space(self.single_action_space, N) if _batch_space
+                             else self.single_action_space)
+        self.is_vector_env = True
         self._ndays = g0.num_days_in_date_range
         self._day0 = g0.date_range[0]
         if self._realbank is not None:

@@ -45,6 +45,8 @@ from sustaingym_amd import envs, spaces
 assert issubclass(envs.EVChargingEnv, gymnasium.Env)
 assert issubclass(envs.DiscreteActionWrapper, gymnasium.ActionWrapper)
 assert issubclass(envs.MultiAgentEVChargingEnv, pettingzoo.ParallelEnv)
+import gymnasium.vector
+assert issubclass(envs.EVChargingVectorEnv, gymnasium.vector.VectorEnv)
 assert registry['sustaingym/EVCharging-v0'] == 'sustaingym_amd.envs:EVChargingEnv'
 assert 'sustaingym_amd/EVCharging-v0' in registry
 
@@ -92,6 +94,9 @@ def test_reference_bases_when_packages_exist(tmp_path):
     (g / '__init__.py').write_text(FAKE_GYMNASIUM)
     (g / 'spaces.py').write_text("raise ImportError('stand-in without spaces: sustaingym_amd.spaces falls back')\n")
     (g / 'envs' / '__init__.py').write_text('')
+    (g / 'vector').mkdir()
+    (g / 'vector' / '__init__.py').write_text('class VectorEnv:\n    pass\n')
+    (g / 'vector' / 'utils.py').write_text('def batch_space(space, n):\n    return (space, n)\n')
     (g / 'envs' / 'registration.py').write_text(textwrap.dedent('''
         registry = {}
         def register(id, entry_point, **kwargs):
