@@ -1,6 +1,7 @@
 // evc_engine.hip — C-ABI implementation (include/evcharge.h) of the MI355X-native batched
 // EV-charging step engine.  Host-side bookkeeping only; all simulation arithmetic is in the
-// gfx950 kernels of evc_kernels.h / evc_solver.h.  There is no CPU execution path.
+// gfx950 kernels of evc_cquad.h (default streaming kernel), evc_quad.h, evc_kernels.h, evc_solver.h and
+// evc_gen.h (episode generator).  There is no CPU execution path.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
