@@ -54,8 +54,8 @@ def parse_args():
     p.add_argument('--single-device', action='store_true',
                    help='testing aid: every rank uses cuda:0 (needs --backend gloo)')
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-envs', type=int, default=2048)
-    p.add_argument('--cpu-steps', type=int, default=96)
+    p.add_argument('--cpu-envs', type=int, default=8192)
+    p.add_argument('--cpu-steps', type=int, default=96, help='minimum timed steps of the cpu_baseline sample')
     p.add_argument('--kernel-timing-steps', type=int, default=288,
                    help='steps timed kernel by kernel for the roofline leg (288 = one whole day: the launch\n'
                         'duration follows the time of day)')
@@ -189,27 +189,43 @@ def main():
         bat = ob.OracleBatch(ob.OracleNetwork(net), cn, k, project)
         bat.set_bank(ns, sess, req, day, moer, autoreset_stride=1)
         bat.reset(np.arange(cn, dtype=np.int32) % P)
-        cores = ob.max_threads()
+        try:                                  # what the host really grants this process (containers cap it)
+            quota = open('/sys/fs/cgroup/cpu.max').read().split()
+            cgroup_cpus = None if quota[0] == 'max' else round(int(quota[0]) / int(quota[1]), 2)
+        except Exception:
+            cgroup_cpus = None
+        host = {'cpu_count': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)), 'cgroup_cpus': cgroup_cpus,
+                'omp_max_threads': ob.max_threads()}
+        # one thread per CPU this process may actually use (more threads than the cgroup quota only get throttled)
+        cores = max(1, min(ob.max_threads(), host['affinity'], int(np.ceil(cgroup_cpus)) if cgroup_cpus else 1 << 30))
         acts = [r[:cn].cpu().numpy() for r in ring]
-        # skip the empty early-morning periods so that the sample has plugged-in EVs
+        # skip the empty early-morning periods so that the sample has plugged-in EVs; their rate sizes the
+        # timed sample to ~3 s of wall time on whatever host this is (bounded: --cpu-steps .. 2304 steps = 8 days)
+        t1 = time.perf_counter()
         for i in range(96):
-            bat.step(acts[i % len(acts)], autoreset=True, debug=False)
+            bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=cores)
+        rate0 = cn * 96 / (time.perf_counter() - t1)
+        cs = int(min(2304, max(cs, 3.0 * rate0 / cn)))
         t1 = time.perf_counter()
         for i in range(cs):
-            bat.step(acts[i % len(acts)], autoreset=True, debug=False)
+            bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=cores)
         dt = time.perf_counter() - t1
-        # the same sample continued on one thread (SURVEY §8d asks for both), bounded to a few seconds
-        c1 = max(1, cs // 4)
+        # the same sample continued on one thread (SURVEY §8d asks for both), ~2 s
+        t1 = time.perf_counter()
+        for i in range(4):
+            bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=1)
+        c1 = int(min(96, max(4, 2.0 / ((time.perf_counter() - t1) / 4))))
         t1 = time.perf_counter()
         for i in range(c1):
             bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=1)
         dt1 = time.perf_counter() - t1
+        first = 97
         cpu_baseline = {'value': round(cn * cs / dt, 1), 'unit': 'env-steps/s', 'cores': cores,
                         'kind': 'port',
-                        'sample': f'{cn} envs x {cs} steps (periods 97..{96 + cs}) of the same workload, '
-                                  f'oracle/ C restatement, OpenMP over envs',
+                        'sample': f'{cn} envs x {cs} steps (from period {first} on, across autoresets) of the same '
+                                  f'workload, {dt:.1f} s, oracle/ C restatement, OpenMP over envs with {cores} threads',
                         'single_thread_value': round(cn * c1 / dt1, 1),
-                        'single_thread_sample': f'{cn} envs x {c1} steps (periods {97 + cs}..{96 + cs + c1}), 1 thread'}
+                        'single_thread_sample': f'{cn} envs x {c1} steps, {dt1:.1f} s, 1 thread', 'host': host}
 
     # Reset-path row, reported beside the headline: refill the whole episode bank with
     # the on-device GMM generator (after the timed region; the bank is not used again).
