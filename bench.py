@@ -189,15 +189,16 @@ def main():
         bat = ob.OracleBatch(ob.OracleNetwork(net), cn, k, project)
         bat.set_bank(ns, sess, req, day, moer, autoreset_stride=1)
         bat.reset(np.arange(cn, dtype=np.int32) % P)
-        try:                                  # what the host really grants this process (containers cap it)
+        # one thread per CPU this process may actually use (more threads than the cgroup quota only get
+        # throttled): oracle.binding.default_threads
+        try:
             quota = open('/sys/fs/cgroup/cpu.max').read().split()
             cgroup_cpus = None if quota[0] == 'max' else round(int(quota[0]) / int(quota[1]), 2)
         except Exception:
             cgroup_cpus = None
         host = {'cpu_count': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)), 'cgroup_cpus': cgroup_cpus,
                 'omp_max_threads': ob.max_threads()}
-        # one thread per CPU this process may actually use (more threads than the cgroup quota only get throttled)
-        cores = max(1, min(ob.max_threads(), host['affinity'], int(np.ceil(cgroup_cpus)) if cgroup_cpus else 1 << 30))
+        cores = ob.default_threads()
         acts = [r[:cn].cpu().numpy() for r in ring]
         # skip the empty early-morning periods so that the sample has plugged-in EVs; their rate sizes the
         # timed sample to ~3 s of wall time on whatever host this is (bounded: --cpu-steps .. 2304 steps = 8 days)

@@ -252,7 +252,7 @@ class OracleBatch:
         else:
             disc, cont = None, np.ascontiguousarray(actions, dtype=np.float32)
         lib().orc_batch_step(self.handle, _p(cont), _p(disc), bins, int(autoreset), self.stride,
-                             threads, _p(out['obs']), _p(out['reward']), _p(out['terminated']),
+                             threads if threads > 0 else default_threads(), _p(out['obs']), _p(out['reward']), _p(out['terminated']),
                              _p(out['breakdown']), _p(out['final_obs']), _p(out.get('pilots')),
                              _p(out.get('rates')), _p(out.get('projected')), _p(out['status']))
         return out
@@ -299,6 +299,27 @@ class OracleGenerator:
 
 def max_threads() -> int:
     return lib().orc_max_threads()
+
+
+_DEFAULT_THREADS = None
+
+
+def default_threads() -> int:
+    """One OpenMP thread per CPU this process may really use: OpenMP's own default counts the machine's
+    hardware threads, which a container's cgroup quota (the GPU boxes grant 16 of 256) only throttles."""
+    global _DEFAULT_THREADS
+    if _DEFAULT_THREADS is None:
+        import math
+        import os
+        n = min(max_threads(), len(os.sched_getaffinity(0)))
+        try:
+            quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+            if quota != 'max':
+                n = min(n, max(1, math.ceil(int(quota) / int(period))))
+        except Exception:
+            pass
+        _DEFAULT_THREADS = max(1, n)
+    return _DEFAULT_THREADS
 
 
 class OracleBattery:
