@@ -185,7 +185,7 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob
-        cn, cs = args.cpu_envs, args.cpu_steps
+        cn, cs = min(args.cpu_envs, N), args.cpu_steps
         bat = ob.OracleBatch(ob.OracleNetwork(net), cn, k, project)
         bat.set_bank(ns, sess, req, day, moer, autoreset_stride=1)
         bat.reset(np.arange(cn, dtype=np.int32) % P)
