@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         const unsigned ebase = env * n;
         const unsigned obase = env * F;                     // observation row
         const QuadRaw cur = nxt;
-        nxt = issue(quad + walk.stride);
+        if (quad + walk.stride < walk.hi) nxt = issue(quad + walk.stride);   // nothing to fetch after the last quad
 
         const v4u s0 = cur.s0, s1 = cur.s1;
         unsigned meta[kSlots];
