@@ -19,7 +19,8 @@ a, b = make('dense'), make('compact')
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 ring = [torch.rand((N, n), device='cuda', generator=g) for _ in range(8)]
 worst_r, worst_o, bad_int, peak = 0.0, 0.0, 0, 0
-for t in range(300):
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+for t in range(steps):
     oa = {k: v.clone() for k, v in a.step(ring[t % 8]).items()}
     ob = b.step(ring[t % 8])
     bad_int += int((oa['terminated'] != ob['terminated']).sum()) + int((oa['obs'][:, n:2*n] != ob['obs'][:, n:2*n]).sum())
