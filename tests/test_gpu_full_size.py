@@ -1,11 +1,11 @@
 """Full BASELINE sizes on the GPU (configs[1..2]: 65 536 batched environments, Caltech and JPL).
 
-The oracle cannot step 65 536 x 288 environment-steps in test time, so parity at full size is
-established through (i) a random SAMPLE of environments replayed on the oracle with the same
-episodes and actions, and (ii) size-independent invariants over the whole batch: the reward
-identity reward = profit - carbon - excess summed over the episode, energy conservation of every
+Parity at full size is established three ways: (i) a random SAMPLE of environments replayed on the
+oracle with the same episodes and actions, (ii) size-independent invariants over the whole batch: the
+reward identity reward = profit - carbon - excess summed over the episode, energy conservation of every
 battery, the 288-step episode length, and agreement of the two kernel families
-(4-environments-per-wavefront vs 1-environment-per-wavefront)."""
+(4-environments-per-wavefront vs 1-environment-per-wavefront), and (iii) bench.py's own workload
+replayed in full by the oracle for a day and the episode boundary, every output compared."""
 import numpy as np
 import pytest
 
@@ -88,3 +88,42 @@ def test_full_size_sampled_parity_and_invariants(site, monkeypatch):
     assert np.all(dep == -1) or np.all(rem[dep != -1] >= -1e-9)
     eng.close()
     eng_wave.close()
+
+
+def test_bench_workload_every_output_against_the_oracle():
+    """bench.py's own workload at its full size — 65 536 Caltech environments, 8192-episode bank, device
+    autoreset, projection on, U[0,1) actions — replayed by the oracle (one OpenMP thread per granted CPU
+    steps the batch in ~40 ms): every output of every step over one whole day plus the episode boundary."""
+    import torch
+    from sustaingym_amd.engine import StepEngine
+    from sustaingym_amd.network import caltech_acn
+    from sustaingym_amd.synthetic import synthetic_episodes, synthetic_moer
+    net = caltech_acn()
+    N, n, P = 65536, 54, 8192
+    ns, sess, req, day = synthetic_episodes(P, n, seed=1000, stride=64, moer_days=32)    # = bench.py, rank 0
+    moer = synthetic_moer(32, seed=7)
+    eng = StepEngine(net, N, project_action=True, autoreset=True, bank_slots=P, max_sessions=64, moer_days=32)
+    eng.upload_moer(moer)
+    eng.upload_episodes(ns, sess, req, day)
+    eng.set_autoreset_stride(1)
+    orc = ob.OracleBatch(ob.OracleNetwork(net), N, 36, True)
+    orc.set_bank(ns, sess, req, day, moer, autoreset_stride=1)
+    slots = (np.arange(N) % P).astype(np.int32)
+    assert np.array_equal(eng.reset(slots=slots, host=True), orc.reset(slots))
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(1234)
+    ring = [torch.rand((N, n), device='cuda', generator=gen) for _ in range(4)]
+    ring_h = [r.cpu().numpy() for r in ring]
+    for t in range(300):
+        g = {k: v.cpu().numpy() for k, v in eng.step(ring[t % 4]).items()}
+        o = orc.step(ring_h[t % 4], autoreset=True, debug=False)
+        assert np.array_equal(g['terminated'], o['terminated']), t
+        assert np.array_equal(g['obs'][:, n:], o['obs'][:, n:]), t              # est_departures, MOER, timestep
+        np.testing.assert_allclose(g['obs'][:, :n], o['obs'][:, :n], rtol=1e-6, atol=1e-6, err_msg=f't={t}')
+        np.testing.assert_allclose(g['reward'], o['reward'], rtol=1e-9, atol=1e-12, err_msg=f't={t}')
+        if o['terminated'].any():
+            m = o['terminated'].astype(bool)
+            np.testing.assert_allclose(g['final_obs'][m], o['final_obs'][m], rtol=1e-6, atol=1e-6)
+    met = eng.read_metrics()
+    assert met['episodes_finished'] == N and met['envs_with_status'] == 0
+    eng.close()
