@@ -90,16 +90,17 @@ def test_full_size_sampled_parity_and_invariants(site, monkeypatch):
     eng_wave.close()
 
 
-def test_bench_workload_every_output_against_the_oracle():
-    """bench.py's own workload at its full size — 65 536 Caltech environments, 8192-episode bank, device
+@pytest.mark.parametrize('site', ['caltech', 'jpl'])
+def test_bench_workload_every_output_against_the_oracle(site):
+    """bench.py's own workload (also with --site jpl) at its full size — 65 536 environments, 8192-episode bank, device
     autoreset, projection on, U[0,1) actions — replayed by the oracle (one OpenMP thread per granted CPU
     steps the batch in ~40 ms): every output of every step over one whole day plus the episode boundary."""
     import torch
     from sustaingym_amd.engine import StepEngine
-    from sustaingym_amd.network import caltech_acn
+    from sustaingym_amd.network import site_str_to_site
     from sustaingym_amd.synthetic import synthetic_episodes, synthetic_moer
-    net = caltech_acn()
-    N, n, P = 65536, 54, 8192
+    net = site_str_to_site(site)
+    N, n, P = 65536, net.num_stations, 8192
     ns, sess, req, day = synthetic_episodes(P, n, seed=1000, stride=64, moer_days=32)    # = bench.py, rank 0
     moer = synthetic_moer(32, seed=7)
     eng = StepEngine(net, N, project_action=True, autoreset=True, bank_slots=P, max_sessions=64, moer_days=32)
