@@ -1,7 +1,7 @@
 # The bench.py workload itself (N = 65 536, 8192-episode bank, autoreset, projection on) replayed by the
 # C oracle: every output of every step compared for two days.
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
 import numpy as np, torch
 from oracle.binding import OracleBatch, OracleNetwork
 from sustaingym_amd.engine import StepEngine

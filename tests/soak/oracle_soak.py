@@ -1,7 +1,7 @@
 # GPU (lean kernels, projection on) vs the C oracle on device-generated GMM days at scale: counts
-# instead of asserting.  Usage: python tools/scratch/oracle_soak.py [site] [N] [seeds]
+# instead of asserting.  Usage: python tests/soak/oracle_soak.py [site] [N] [seeds]
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
 import numpy as np
 from oracle.binding import OracleBatch, OracleNetwork
 from sustaingym_amd.engine import StepEngine
