@@ -273,9 +273,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
                 for (int c = 0; c < kSlots; c++) st_gid[c] = valid[c] ? (int)(st_info[st[c]] & 0x7fu) : -1;
                 unsigned cap_viol;
                 bool hard = quad_exact_rows(P, net, q, m, st_gid, y, undecided, cap_viol);
-                bool nonsimple = row_any(hard && !((P.simple_rows >> q) & 1u), row);
                 bool anyviol = row_any(hard, row);
-                bool fill = undecided && anyviol && !nonsimple;
+                // Class caps are filled whenever one is violated, also beside violated multi-class rows:
+                // if the point projected onto box and caps satisfies every row it is the projection
+                // (relaxation argument); what remains violated goes to the slow kernel.
+                bool fill = undecided && cap_viol != 0u;
                 if (__builtin_expect(__ballot(fill) != 0ull, 0)) {
                     for (int g = 0; g < P.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
@@ -283,7 +285,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
                     }
                     unsigned cv2;
                     const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, 1e-6), row);
-                    nonsimple = nonsimple || (fill && still);     // could not be settled here
                     anyviol = anyviol && !(fill && !still);
                 }
                 const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel

@@ -468,9 +468,10 @@ __global__ __launch_bounds__(256) void step_kernel(Params P, StepIO io) {
                 unsigned long long vrows = exact_rows(P, net, ln, lane, y, cap_viol);
                 if (vrows != 0ull) {
                     bool solved = false;
-                    if ((vrows & ~(unsigned long long)P.simple_rows) == 0ull) {
-                        // 3) only class caps (pod breakers) are violated: closed-form water-filling;
-                        //    exact if the result satisfies every other row (relaxation argument)
+                    if (cap_viol != 0u) {
+                        // 3) class caps (pod breakers) are violated: closed-form water-filling; exact if
+                        //    the result satisfies every row (relaxation argument), also when multi-class
+                        //    rows were violated before the caps were applied
                         double yw = y;
                         for (int g = 0; g < P.G; g++)
                             if ((cap_viol >> g) & 1u)

@@ -311,9 +311,11 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
                 // row; anything else is queued for the slow kernel.
                 unsigned cap_viol;
                 bool hard = quad_exact_rows(P, net, q, m, st_gid, y, undecided, cap_viol);
-                bool nonsimple = row_any(hard && !((P.simple_rows >> q) & 1u), row);
                 bool anyviol = row_any(hard, row);
-                bool fill = undecided && anyviol && !nonsimple;
+                // Class caps are filled whenever one is violated, also beside violated multi-class rows:
+                // if the point projected onto box and caps satisfies every row it is the projection
+                // (relaxation argument); what remains violated goes to the slow kernel.
+                bool fill = undecided && cap_viol != 0u;
                 if (__ballot(fill) != 0ull) {
                     // y is updated in place: rows that cannot be settled here are queued and the
                     // slow kernel recomputes them from the stored state
@@ -324,7 +326,6 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
                     unsigned cv2;
                     // re-verify every row on the snapped values (snapping moves a class sum by < n 2^-17 A)
                     const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, 1e-6), row);
-                    nonsimple = nonsimple || (fill && still);     // could not be settled here
                     anyviol = anyviol && !(fill && !still);
                 }
                 const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel

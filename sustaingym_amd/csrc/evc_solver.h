@@ -254,7 +254,8 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
         SOLVER_SYNC();
 
         // (a) the screen of the streaming kernel may have been merely inconclusive: exact test of
-        //     the box clip; (b) only class caps (pod breakers) violated: closed-form water-filling
+        //     the box clip; (b) class caps (pod breakers) violated: closed-form water-filling, exact if
+        //     every row holds afterwards (relaxation argument)
         bool settled = false;
         {
             const double y0 = fmin(ln.b, ln.h);
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
             ln.y = y0;
             if (vrows == 0ull) {
                 settled = true;
-            } else if ((vrows & ~(unsigned long long)P.simple_rows) == 0ull) {
+            } else if (cap_viol != 0u) {          // caps first, also beside violated multi-class rows
                 double yw = y0;
                 for (int g = 0; g < G; g++)
                     if ((cap_viol >> g) & 1u)

@@ -58,3 +58,31 @@ def assert_step_parity(g, o, n, tag='', float_rtol=1e-9, check_debug=True):
     np.testing.assert_allclose(g['reward'], o['reward'], rtol=float_rtol, atol=1e-13, err_msg=tag)
     np.testing.assert_allclose(g['breakdown'], o['breakdown'], rtol=float_rtol, atol=1e-12, err_msg=tag)
     assert F == 2 * n + (F - 2 * n)
+
+
+def random_network(rng, tag='fuzz'):
+    """A random network descriptor: station count 3..64 (odd ones too), 1..14 station classes (every WORDS
+    instantiation), 1..16 rows — class caps ("pods") first, then rows over several classes with mixed
+    signs —, mixed AV / CC EVSEs.  Used by tests/soak/network_fuzz.py and test_gpu_synthetic_network.py."""
+    from sustaingym_amd.network import ChargingNetwork
+    n = int(rng.integers(3, 65)); G = int(rng.integers(1, min(14, n) + 1)); m = int(rng.integers(1, 17))
+    cls = np.sort(rng.integers(0, G, n)); cls[:G] = np.arange(G); cls = np.sort(cls)
+    G = len(np.unique(cls))
+    phase_of = rng.choice([30.0, -90.0, 150.0], size=G)
+    rows, mags = [], []
+    for r in range(m):
+        coef = np.zeros(G)
+        if r < min(G, m // 2 + 1):                     # class caps ("pods"): simple rows
+            coef[r] = 1.0
+            size = int((cls == r).sum())
+            mags.append(max(20.0, 32.0 * size * float(rng.uniform(0.3, 0.9))))
+        else:
+            pick = rng.choice(G, size=min(G, int(rng.integers(1, 5))), replace=False)
+            coef[pick] = rng.choice([1.0, -1.0, 0.5, 0.25], size=len(pick))
+            load = float(np.abs(coef[cls]).sum()) * 32.0
+            mags.append(max(20.0, load * float(rng.uniform(0.25, 0.8))))
+        rows.append(coef[cls])
+    return ChargingNetwork(site=tag, station_ids=[f'S{i:02d}' for i in range(n)],
+                           constraint_matrix=np.array(rows), phase_angles=phase_of[cls], magnitudes=np.array(mags),
+                           constraint_names=[f'r{i}' for i in range(m)],
+                           evse_kind=(rng.random(n) < 0.2).astype(np.uint8))

@@ -1,0 +1,40 @@
+# Random network descriptors (station count incl. odd, class count 1..14 -> every WORDS instantiation,
+# row count 1..16, mixed AV / CC) through both layouts and both kernel flavours against the oracle.
+# Usage: python tests/soak/network_fuzz.py [cases] [seed]
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))                    # tests/
+import numpy as np
+from helpers import assert_step_parity, make_pair, make_workload, random_network
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+done = 0
+for case in range(cases):
+    net = random_network(rng, f'fuzz{case}')
+    n, m = net.num_stations, len(net.magnitudes)
+    N = 64
+    wl = make_workload(net, N, seed=100 + case, busy=bool(case % 2), stride=96)
+    for layout in ('compact', 'dense'):
+        os.environ['EVC_LAYOUT'] = layout
+        for project in (True, False):
+            eng, ob = make_pair(net, N, wl, project=project, debug=True)
+            lean, _ = make_pair(net, N, wl, project=project, debug=False)
+            assert np.array_equal(eng.reset(host=True), ob.reset()); lean.reset(host=True)
+            arng = np.random.default_rng(case)
+            slow = 0
+            for t in range(288):
+                a = arng.random((N, n), dtype=np.float32)
+                if t % 50 == 25: a[::3] = 1.0
+                g = eng.step(a); o = ob.step(a)
+                assert_step_parity(g, o, n, tag=f'case {case} n={n} m={m} {layout} project={project} t={t}')
+                l = lean.step(a)
+                assert np.array_equal(l['terminated'], g['terminated'])
+                np.testing.assert_allclose(l['obs'], g['obs'], rtol=0, atol=2e-5)
+                np.testing.assert_allclose(l['reward'], g['reward'], rtol=1e-11, atol=1e-13)
+                if project: slow += eng.last_slow_count()
+            noconv = int(((eng.env_scalars()['status'] & 2) != 0).sum())
+            eng.close(); lean.close()
+            done += 1
+            print(f'case {case}: n={n} m={m} {layout} project={project}: ok (slow-queue solves {slow}, noconv {noconv})', flush=True)
+print('all', done, 'runs match the oracle')

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_step_parity, make_workload
+from helpers import assert_step_parity, make_workload, random_network
 from sustaingym_amd.network import ChargingNetwork
 
 pytestmark = pytest.mark.gpu
@@ -69,3 +69,29 @@ def test_synthetic_64_station_network(layout, project):
     if project:
         assert slow > 0                                    # the slow kernel took part
     eng.close(); lean.close()
+
+
+def test_caps_violated_beside_multi_class_rows():
+    """Found by tests/soak/network_fuzz.py (seed 0, case 1): six single-station classes, each with a cap row,
+    plus nine rows over several classes.  Box-clipped actions violate caps AND multi-class rows at once while
+    the projection only needs the caps; the slow kernel used to hand this to the conic-dual Newton (more
+    violated rows than it keeps active) and raised EVC_STATUS_PROJ_NOCONV with a wrong schedule.  Caps are now
+    filled first everywhere (relaxation argument), the rest only if rows stay violated."""
+    from helpers import make_pair
+    rng = np.random.default_rng(0)
+    random_network(rng)                                   # case 0 of the fuzz sequence
+    net = random_network(rng, 'fuzz1')
+    n = net.num_stations
+    assert n == 6 and len(net.magnitudes) == 15
+    N = 64
+    wl = make_workload(net, N, seed=101, busy=True, stride=96)
+    eng, ob = make_pair(net, N, wl, project=True, debug=True)
+    assert np.array_equal(eng.reset(host=True), ob.reset())
+    arng = np.random.default_rng(1)
+    for t in range(288):
+        a = arng.random((N, n), dtype=np.float32)
+        if t % 50 == 25:
+            a[::3] = 1.0
+        assert_step_parity(eng.step(a), ob.step(a), n, tag=f't={t}')
+    assert not (eng.env_scalars()['status'] & 2).any()
+    eng.close()
