@@ -666,12 +666,22 @@ int evc_download_episodes(evc_engine* e, int32_t first_slot, int32_t count, int3
     if (n_sessions) HIP_TRY(hipMemcpy(n_sessions, e->d_nsess + first_slot, sizeof(int) * count, hipMemcpyDeviceToHost));
     if (moer_day) HIP_TRY(hipMemcpy(moer_day, e->d_slot_moer + first_slot, sizeof(int) * count, hipMemcpyDeviceToHost));
     if (max_profit) HIP_TRY(hipMemcpy(max_profit, e->d_maxprofit + first_slot, sizeof(double) * count, hipMemcpyDeviceToHost));
-    if (sessions)
-        HIP_TRY(hipMemcpy2D(sessions, sizeof(evc_session) * (size_t)stride, e->d_sessions + first_slot * S,
-                            sizeof(evc_session) * S, sizeof(evc_session) * S, count, hipMemcpyDeviceToHost));
-    if (requested)
-        HIP_TRY(hipMemcpy2D(requested, sizeof(double) * (size_t)stride, e->d_requested + first_slot * S,
-                            sizeof(double) * S, sizeof(double) * S, count, hipMemcpyDeviceToHost));
+    // rows of the bank are contiguous when the caller's stride equals max_sessions (the usual case): one
+    // plain copy; a pitched copy only for wider host rows
+    if (sessions) {
+        if ((size_t)stride == S)
+            HIP_TRY(hipMemcpy(sessions, e->d_sessions + first_slot * S, sizeof(evc_session) * S * count, hipMemcpyDeviceToHost));
+        else
+            HIP_TRY(hipMemcpy2D(sessions, sizeof(evc_session) * (size_t)stride, e->d_sessions + first_slot * S,
+                                sizeof(evc_session) * S, sizeof(evc_session) * S, count, hipMemcpyDeviceToHost));
+    }
+    if (requested) {
+        if ((size_t)stride == S)
+            HIP_TRY(hipMemcpy(requested, e->d_requested + first_slot * S, sizeof(double) * S * count, hipMemcpyDeviceToHost));
+        else
+            HIP_TRY(hipMemcpy2D(requested, sizeof(double) * (size_t)stride, e->d_requested + first_slot * S,
+                                sizeof(double) * S, sizeof(double) * S, count, hipMemcpyDeviceToHost));
+    }
     return EVC_OK;
 }
 
