@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 2
+#define EVC_ABI_VERSION 3
 
 #define EVC_MAX_STATIONS     64   /* one gfx950 wavefront per environment            */
 #define EVC_MAX_CONSTRAINTS  32   /* rows of ChargingNetwork.constraint_matrix       */
@@ -60,6 +60,12 @@ extern "C" {
 /* evc_create flags */
 #define EVC_FLAG_PROJECT_ACTION  (1u << 0)  /* env.py:118 project_action_in_env (default True) */
 #define EVC_FLAG_AUTORESET       (1u << 1)  /* gymnasium 0.28 VectorEnv autoreset semantics     */
+/* Battery model = acnportal Linear2StageBattery(charge_calculation=...).  The reference constructs the
+ * battery without that argument (event_generation.py:173-176), i.e. with acnportal's default
+ * "continuous" (maximum rate falls linearly above the transition SoC, integrated exactly over the
+ * period): that is what the engine simulates unless this flag selects the legacy "stepwise" model
+ * (rate limit frozen at its start-of-period value). */
+#define EVC_FLAG_BATTERY_STEPWISE (1u << 2)
 
 /* action encodings for evc_step */
 #define EVC_ACTION_F32       0   /* float32[N][n] in [0,1]            (env.py:171-172)          */

@@ -17,6 +17,9 @@ _LIB_PATH = os.path.join(_HERE, 'libevc_oracle.so')
 MAX_STATIONS = 64
 MOER_ROWS, MOER_COLS = 289, 37
 
+# acnportal Linear2StageBattery(charge_calculation=...): ORC_BATTERY_* of evc_oracle.h
+BATTERY_MODELS = {'continuous': 0, 'stepwise': 1}
+
 SESSION_DTYPE = np.dtype([('arrival', '<i2'), ('departure', '<i2'),
                           ('est_departure', '<i2'), ('station', '<i2')])
 
@@ -64,6 +67,8 @@ def lib() -> C.CDLL:
         L.orc_env_create.restype = vp
         L.orc_env_create.argtypes = [vp, i32, i32]
         L.orc_env_destroy.argtypes = [vp]
+        L.orc_env_set_battery_model.argtypes = [vp, i32]
+        L.orc_batch_set_battery_model.argtypes = [vp, i32]
         L.orc_env_reset.argtypes = [vp, i32, vp, vp, vp, vp]
         L.orc_env_step.argtypes = [vp, vp, vp, C.POINTER(StepResult)]
         L.orc_env_step_discrete.argtypes = [vp, vp, i32, vp, C.POINTER(StepResult)]
@@ -146,13 +151,15 @@ def pack_sessions(arrival, departure, est_departure, station) -> np.ndarray:
 class OracleEnv:
     """One scalar environment (EVChargingEnv restatement)."""
 
-    def __init__(self, onet: OracleNetwork, moer_forecast_steps: int = 36, project: bool = True):
+    def __init__(self, onet: OracleNetwork, moer_forecast_steps: int = 36, project: bool = True,
+                 charge_calculation: str = 'continuous'):
         self.onet = onet
         self.n, self.k = onet.n, moer_forecast_steps
         self.F = 2 * self.n + self.k + 2
         self.handle = lib().orc_env_create(onet.handle, moer_forecast_steps, int(project))
         if not self.handle:
             raise RuntimeError('orc_env_create failed')
+        lib().orc_env_set_battery_model(self.handle, BATTERY_MODELS[charge_calculation])
         self._obs = np.zeros(self.F, dtype=np.float32)
 
     def __del__(self):
@@ -206,10 +213,11 @@ class OracleBatch:
     """N scalar environments stepped in a C loop (OpenMP over environments)."""
 
     def __init__(self, onet: OracleNetwork, num_envs: int, moer_forecast_steps: int = 36,
-                 project: bool = True):
+                 project: bool = True, charge_calculation: str = 'continuous'):
         self.onet, self.N, self.n, self.k = onet, num_envs, onet.n, moer_forecast_steps
         self.F = 2 * self.n + self.k + 2
         self.handle = lib().orc_batch_create(onet.handle, num_envs, moer_forecast_steps, int(project))
+        lib().orc_batch_set_battery_model(self.handle, BATTERY_MODELS[charge_calculation])
         self.bank_slots = 0
         self.stride = 1
 

@@ -72,6 +72,7 @@ typedef struct {
 struct orc_env {
     const orc_net* net;
     int k, project;
+    int battery_model;             /* ORC_BATTERY_* (Linear2StageBattery.charge_calculation) */
     ev_t evs[ORC_MAX_SESSIONS];
     int n_evs;
     event_t queue[2 * ORC_MAX_SESSIONS + MAX_TIMESTEP + 8];
@@ -121,6 +122,7 @@ orc_env* orc_env_create(const orc_net* net, int k, int project) {
     return e;
 }
 void orc_env_destroy(orc_env* e) { free(e); }
+void orc_env_set_battery_model(orc_env* e, int model) { e->battery_model = model; }
 int orc_env_t(const orc_env* e) { return e->t; }
 
 /* acnportal EventQueue: heap of (timestamp, event); Event.__lt__ compares precedence.
@@ -220,13 +222,10 @@ void orc_env_reset(orc_env* e, int n_sessions, const orc_session* s, const doubl
     get_observation(e, obs_out); /* env.py:338 */
 }
 
-/* acnportal Linear2StageBattery._charge_stepwise (charge_calculation="stepwise", noise 0)
- * followed by EV.charge; returns the actual charging rate in A. */
-static double ev_charge(ev_t* ev, double pilot, double voltage, double period) {
-    if (pilot == 0.0) {
-        ev->current_charging_rate = 0.0;
-        return 0.0;
-    }
+/* acnportal Linear2StageBattery._charge_stepwise (charge_calculation="stepwise", noise 0): the
+ * legacy model, "should only be used for reproducing results from older versions of acnportal".
+ * Returns the charging power in kW. */
+static double battery_charge_stepwise(ev_t* ev, double pilot, double voltage, double period) {
     double rate_to_full = (ev->capacity - ev->current_charge) / (period / 60.0);
     double soc = ev->current_charge / ev->capacity;
     double pilot_kw = pilot * voltage / 1000.0;
@@ -237,9 +236,49 @@ static double ev_charge(ev_t* ev, double pilot, double voltage, double period) {
         double taper = (1.0 - soc) / (1.0 - TRANSITION_SOC) * ev->max_power;
         charge_power = fmin(fmin(pilot_kw, taper), rate_to_full);
     }
-    /* "ensure that noise does not cause the battery to violate any hard limits" */
-    charge_power = fmin(fmin(fmin(charge_power, pilot_kw), ev->max_power), rate_to_full);
     ev->current_charge += charge_power * (period / 60.0);
+    return charge_power;
+}
+
+/* acnportal Linear2StageBattery._charge (charge_calculation="continuous", the constructor's DEFAULT
+ * in acnportal >= 0.3; the reference builds the battery without that argument,
+ * event_generation.py:173-176), noise 0.  All arithmetic in state of charge, in acnportal's
+ * operation order: the maximum rate is constant up to the transition SoC and then falls linearly to 0
+ * at SoC 1, integrated exactly over the period (hence the exponentials).  Returns kW. */
+static double battery_charge_continuous(ev_t* ev, double pilot, double voltage, double period) {
+    double soc = ev->current_charge / ev->capacity;
+    /* pilot and maximum rate as changes of SoC per period */
+    double pilot_dsoc = pilot * voltage / 1000.0 / ev->capacity / (60.0 / period);
+    double max_dsoc = ev->max_power / ev->capacity / (60.0 / period);
+    if (pilot_dsoc > max_dsoc) pilot_dsoc = max_dsoc;
+    /* SoC at which a battery charging at pilot_dsoc meets the falling maximum-rate line */
+    double pilot_transition_soc =
+        TRANSITION_SOC + (pilot_dsoc - max_dsoc) / max_dsoc * (TRANSITION_SOC - 1.0);
+    double curr_soc;
+    if (soc < pilot_transition_soc) {
+        if (1.0 <= (pilot_transition_soc - soc) / pilot_dsoc) {
+            curr_soc = pilot_dsoc + soc; /* stays in the constant-rate region */
+        } else {                          /* crosses into the ramp-down region within the period */
+            curr_soc = 1.0 + exp((pilot_dsoc + soc - pilot_transition_soc) / (pilot_transition_soc - 1.0)) *
+                                 (pilot_transition_soc - 1.0);
+        }
+    } else {
+        curr_soc = 1.0 + exp(pilot_dsoc / (pilot_transition_soc - 1.0)) * (soc - 1.0);
+    }
+    double dsoc = curr_soc - soc;
+    ev->current_charge = curr_soc * ev->capacity;
+    return dsoc * ev->capacity / (period / 60.0); /* average power over the period */
+}
+
+/* Linear2StageBattery.charge followed by acnportal EV.charge; returns the actual charging rate (A). */
+static double ev_charge(ev_t* ev, double pilot, double voltage, double period, int battery_model) {
+    if (pilot == 0.0) {
+        ev->current_charging_rate = 0.0;
+        return 0.0;
+    }
+    double charge_power = battery_model == ORC_BATTERY_STEPWISE
+                              ? battery_charge_stepwise(ev, pilot, voltage, period)
+                              : battery_charge_continuous(ev, pilot, voltage, period);
     double charge_rate = charge_power * 1000.0 / voltage;
     /* EV.charge */
     ev->energy_delivered += (charge_rate * voltage / 1000.0) * (period / 60.0);
@@ -287,7 +326,7 @@ static int simulator_step(orc_env* e, const double* pilots, double* rates) {
     /* network.update_pilots(pilot_signals, _iteration, period): EVSE.set_pilot -> EV.charge */
     for (int i = 0; i < n; i++) {
         int idx = e->evse_ev[i];
-        rates[i] = (idx >= 0) ? ev_charge(&e->evs[idx], pilots[i], VOLTAGE, TIMESTEP_DURATION) : 0.0;
+        rates[i] = (idx >= 0) ? ev_charge(&e->evs[idx], pilots[i], VOLTAGE, TIMESTEP_DURATION, e->battery_model) : 0.0;
     }
     e->iteration += 1;
     /* event_queue.get_current_events(_iteration): pop everything with timestamp <= it FIRST,
@@ -483,6 +522,10 @@ void orc_batch_destroy(orc_batch* b) {
     free(b->slot);
     batch_free_bank(b);
     free(b);
+}
+
+void orc_batch_set_battery_model(orc_batch* b, int model) {
+    for (int i = 0; i < b->N; i++) orc_env_set_battery_model(b->envs[i], model);
 }
 
 void orc_batch_set_bank(orc_batch* b, int bank_slots, int stride, const int32_t* n_sessions,

@@ -16,12 +16,13 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SUSTAINGYM_AMD_LIB', os.path.join(_PKG, 'libevcharge_hip.so'))
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'evcharge.h')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_STATIONS, MAX_CONSTRAINTS, MAX_GROUPS, MAX_SESSIONS = 64, 32, 16, 256
 MOER_ROWS, MOER_COLS, EPISODE_STEPS = 289, 37, 288
 
 FLAG_PROJECT_ACTION = 1 << 0
 FLAG_AUTORESET = 1 << 1
+FLAG_BATTERY_STEPWISE = 1 << 2    # acnportal Linear2StageBattery(charge_calculation='stepwise'), the legacy model
 ACTION_F32, ACTION_DISCRETE, ACTION_GREEDY = 0, 1, 2
 
 STATUS_OCCUPIED = 1 << 0

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
     const Win r_sess{r_win, P.off_sess}, r_req{r_win, P.off_req};
 
     const bool greedy = DBG && io.action_kind == EVC_ACTION_GREEDY;
+    const bool stepwise = P.battery_stepwise != 0;
     const unsigned nquads = (N + 3u) >> 2;
     EnvWalker walk((int)nquads, 4);
     // Raw loads of one quad, issued one iteration ahead (software prefetch): the waves of this kernel
@@ -298,15 +299,33 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         double pilot[kSlots], amps[kSlots];
 #pragma unroll
         for (int c = 0; c < kSlots; c++) { pilot[c] = 0.0; amps[c] = 0.0; }
+        bool cross[kSlots];
+        double rem_in[kSlots];
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) { cross[c] = false; rem_in[c] = 0.0; }
         auto charge = [&](int c) {
             const unsigned info = st_info[st[c]];
             const double pl = legal_pilot(y[c], (info >> 7) != 0u);     // y = 0 on invalid entries
             pilot[c] = pl;
-            amps[c] = charge_ev(pl, rem[c]);                             // every entry is a plugged-in EV
-            if (live && valid[c]) obs_row[st[c]].amps = amps[c];
+            rem_in[c] = rem[c];
+            amps[c] = charge_ev_main(pl, rem[c], stepwise, cross[c]);    // every entry is a plugged-in EV
         };
 #pragma unroll
         for (int c = 0; c < NS; c++) charge(c);
+        {   // the period in which an EV reaches the ramp-down line (continuous battery model): once per
+            // session at most, so the exponential sits behind a wave-uniform branch
+            bool any_cross = false;
+#pragma unroll
+            for (int c = 0; c < NS; c++) any_cross = any_cross || cross[c];
+            if (__builtin_expect(__ballot(any_cross) != 0ull, 0)) {
+#pragma unroll
+                for (int c = 0; c < NS; c++)
+                    if (cross[c]) amps[c] = charge_ev_cross(pilot[c], rem_in[c], rem[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NS; c++)
+            if (live && valid[c]) obs_row[st[c]].amps = amps[c];
         double pilot_st[kSlots];                   // station-side pilots (station_pilots only)
 #pragma unroll
         for (int j = 0; j < kSlots; j++) pilot_st[j] = 0.0;

@@ -91,6 +91,7 @@ struct Params {
     // only those: traffic and work scale with the EVs present, not with the stations), depest packs
     // pack_entry(), and A sits in bits 16..22 of the status word.
     int compact;
+    int battery_stepwise;    // Linear2StageBattery charge_calculation: 0 = "continuous" (acnportal default), 1 = "stepwise"
     unsigned long long group_mask[EVC_MAX_GROUPS];  // lanes of each station class
     unsigned long long cc_mask;                     // lanes with a ClipperCreek EVSE
     // "simple" rows load a single station class (e.g. the Caltech pod breakers): they cap that
@@ -306,21 +307,86 @@ __device__ __forceinline__ double legal_pilot(double y, bool is_cc) {
     return is_cc ? cc : av;
 }
 
-// acnportal Linear2StageBattery._charge_stepwise + EV.charge for a battery of capacity 100 kWh,
-// max power 100 kW, whose headroom equals the EV's remaining demand `rem` (event_generation.py
-// :173-176 with requested <= 100).  Division-free form of the same formulas:
-//   rate_to_full = rem / (5/60) = 12 rem;  bulk stage (soc < 0.8  <=>  rem > 20): P = min(kw, 100, 12 rem)
-//   taper stage: limit = (1-soc)/(1-0.8)*100 = 5 rem  (< 12 rem)  ->  P = min(kw, 5 rem)
-//   amps = P*1000/208;  delivered += (amps*208/1000)*(5/60) = P/12
-// (agrees with the literal operation order of acnportal to a few ulp).
-// `pilot` must already be 0 for lanes without an EV.  Returns the actual rate (A), updates rem.
-__device__ __forceinline__ double charge_ev(double pilot, double& rem) {
+// acnportal Linear2StageBattery.charge + EV.charge for a battery of capacity 100 kWh, max power 100 kW,
+// transition SoC 0.8, 5-minute periods, 208 V, whose headroom equals the EV's remaining demand `rem`
+// (event_generation.py:173-176 with requested <= 100).  `pilot` is an EVSE-legal pilot (0 or 6..32 A) and
+// must already be 0 for lanes without an EV.  Returns the actual rate (A), updates rem.
+//
+// charge_calculation = "continuous" (acnportal's default, which the reference gets: it passes no argument),
+// `_charge`, restated from state of charge to headroom (rem = 100 (1 - soc), kw = 0.208 pilot <= 6.656 < 100):
+//   pilot_dsoc = kw/1200 per period,  pilot_transition_soc = 1 - 0.002 kw  <=>  headroom rem_T = 0.2 kw
+//   rem - rem_T >= kw/12 : constant-rate region for the whole period      rem' = rem - kw/12
+//   0 < rem - rem_T < kw/12 : reaches the ramp-down line inside the period  rem' = rem_T exp(-(kw/12 - (rem - rem_T)) / rem_T)
+//   rem <= rem_T : ramp-down region, rate proportional to the headroom      rem' = rem exp(-(kw/1200) / (0.002 kw)) = rem e^(-5/12)
+//   amps = (rem - rem') * 12 * 1000 / 208
+// (acnportal evaluates the same expressions on soc ~ 1; the two forms agree to ~1e-14 kWh per period).
+//
+// charge_calculation = "stepwise" (EVC_FLAG_BATTERY_STEPWISE, acnportal's legacy `_charge_stepwise`), division-free:
+//   rate_to_full = 12 rem;  soc < 0.8 (rem > 20): P = min(kw, 100, 12 rem);  else P = min(kw, 5 rem);  rem' = rem - P/12
+
+// exp(u) for u in [-5/12, 0]: Taylor series of degree 11 about the interval's centre (|v| <= 5/24:
+// truncation 1.4e-17 relative), Horner in v.  Only +, * — identical on every lane and run.
+__device__ __forceinline__ double exp_tail(double u) {
+    const double v = u + 5.0 / 24.0;
+    double p = 1.0 / 39916800.0;
+    p = fma(p, v, 1.0 / 3628800.0);
+    p = fma(p, v, 1.0 / 362880.0);
+    p = fma(p, v, 1.0 / 40320.0);
+    p = fma(p, v, 1.0 / 5040.0);
+    p = fma(p, v, 1.0 / 720.0);
+    p = fma(p, v, 1.0 / 120.0);
+    p = fma(p, v, 1.0 / 24.0);
+    p = fma(p, v, 1.0 / 6.0);
+    p = fma(p, v, 0.5);
+    p = fma(p, v, 1.0);
+    p = fma(p, v, 1.0);
+    return p * 0.8119363461506349;          // e^(-5/24)
+}
+
+constexpr double kExpTail = 0.6592406302004438;           // e^(-5/12)
+
+// The part every lane executes.  `cross` is set on lanes in the crossing case, whose rem' / amps the
+// caller finishes with charge_ev_cross() under a wave-uniform branch (at most one period per session).
+__device__ __forceinline__ double charge_ev_main(double pilot, double& rem, bool stepwise, bool& cross) {
     const double kw = pilot * (Consts::VOLTAGE / 1000.0);
-    const double bulk = fmin(12.0 * rem, Consts::BATTERY_MAX_POWER);
-    const double limit = (rem > 20.0) ? bulk : 5.0 * rem;
-    const double p = fmin(kw, limit);
-    rem = rem - p * (1.0 / 12.0);
-    return p * (1000.0 / Consts::VOLTAGE);
+    if (stepwise) {
+        const double bulk = fmin(12.0 * rem, Consts::BATTERY_MAX_POWER);
+        const double limit = (rem > 20.0) ? bulk : 5.0 * rem;
+        const double p = fmin(kw, limit);
+        rem = rem - p * (1.0 / 12.0);
+        cross = false;
+        return p * (1000.0 / Consts::VOLTAGE);
+    }
+    const double rem_t = 0.2 * kw;
+    const double d = kw * (1.0 / 12.0);
+    const double x = rem - rem_t;
+    const bool linear = x >= d;                          // also pilot = 0 (d = rem_t = 0): nothing moves
+    cross = !linear && x > 0.0;
+    const double delivered = linear ? d : rem - rem * kExpTail;
+    rem = linear ? rem - d : rem * kExpTail;
+    return delivered * (12.0 * 1000.0 / Consts::VOLTAGE);
+}
+
+// Crossing case: rem0 = headroom before the period.  Returns amps, sets rem.
+__device__ __forceinline__ double charge_ev_cross(double pilot, double rem0, double& rem) {
+    const double kw = pilot * (Consts::VOLTAGE / 1000.0);
+    const double rem_t = 0.2 * kw;
+    // u = -(kw/12 - (rem0 - rem_t)) / rem_t = rem0 / rem_t - 17/12, in (-5/12, 0)
+    double r = __builtin_amdgcn_rcp(rem_t);              // ~2^-26 relative; two Newton steps -> double precision
+    r = fma(fma(-rem_t, r, 1.0), r, r);
+    r = fma(fma(-rem_t, r, 1.0), r, r);
+    const double u = fmin(fmax(fma(rem0, r, -17.0 / 12.0), -5.0 / 12.0), 0.0);
+    rem = rem_t * exp_tail(u);
+    return (rem0 - rem) * (12.0 * 1000.0 / Consts::VOLTAGE);
+}
+
+// One-call form (slow kernel, wave-per-environment kernels): per-lane branch.
+__device__ __forceinline__ double charge_ev(double pilot, double& rem, bool stepwise) {
+    const double rem0 = rem;
+    bool cross;
+    double amps = charge_ev_main(pilot, rem, stepwise, cross);
+    if (cross) amps = charge_ev_cross(pilot, rem0, rem);
+    return amps;
 }
 
 }  // namespace evc

@@ -396,6 +396,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     P.autoreset = (flags & EVC_FLAG_AUTORESET) ? 1 : 0;
     P.autoreset_stride = 1;
     P.project = (flags & EVC_FLAG_PROJECT_ACTION) ? 1 : 0;
+    P.battery_stepwise = (flags & EVC_FLAG_BATTERY_STEPWISE) ? 1 : 0;
     {
         const char* lay = getenv("EVC_LAYOUT");          // "dense" | "compact" 
         e->compact = lay ? strcmp(lay, "compact") == 0 : kDefaultCompact;

@@ -268,7 +268,7 @@ __device__ __forceinline__ void finish_step(const Params& P, const StepIO& io, c
 
     // ---- acnsim update_pilots: charge the plugged EVs for iteration t1-1 ----
     const bool occupied = r.dep != kEmptyDep;
-    const double amps = charge_ev(occupied ? pilot : 0.0, r.rem);
+    const double amps = charge_ev(occupied ? pilot : 0.0, r.rem, P.battery_stepwise != 0);
     const double total_rate = wave_sum_f64(amps);                    // env.py:445
 
     // ---- env.py:449-452 screen of the PILOT schedule (exact integer class sums, float32 rows) ----

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
     const rsrc_t r_sess = row_rsrc(P.sessions, (unsigned)P.bank_slots * (unsigned)P.max_sessions * 8u);
     const rsrc_t r_req = row_rsrc(P.requested, (unsigned)P.bank_slots * (unsigned)P.max_sessions * 8u);
 
+    const bool stepwise = P.battery_stepwise != 0;
     const unsigned nquads = (N + 3u) >> 2;
     EnvWalker walk((int)nquads, 4);            // XCD-aware walk over quads
     struct QuadLoads {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
 #pragma unroll
             for (int w = 0; w < WORDS; w++) pwords[w] += (st_word[j] == w) ? qp : 0u;
             const bool occupied = dep[j] != kEmptyDep;
-            amps[j] = charge_ev(occupied ? pl : 0.0, rem[j]);
+            amps[j] = charge_ev(occupied ? pl : 0.0, rem[j], stepwise);
             amps_sum += amps[j];
         }
 

@@ -25,12 +25,19 @@ class StepEngine:
 
     Replaces, for a batch, ``EVChargingEnv.__init__/reset/step/close`` of the reference
     (sustaingym/envs/evcharging/env.py:116-176, 293-338, 229-291, 466-470).
+
+    ``charge_calculation`` is the argument of that name of acnportal's ``Linear2StageBattery``: the
+    reference does not pass it (event_generation.py:173-176) and so runs acnportal's default
+    ``'continuous'`` model, the default here; ``'stepwise'`` selects acnportal's legacy model.
     """
 
     def __init__(self, network: ChargingNetwork, num_envs: int, moer_forecast_steps: int = 36,
                  project_action: bool = True, autoreset: bool = False, device: int = 0,
                  bank_slots: int | None = None, max_sessions: int = 128, moer_days: int = 1,
-                 debug_outputs: bool = False):
+                 debug_outputs: bool = False, charge_calculation: str = 'continuous'):
+        if charge_calculation not in ('continuous', 'stepwise'):       # acnportal raises ValueError too
+            raise ValueError("charge_calculation must be 'continuous' (acnportal's default) or 'stepwise'")
+        self.charge_calculation = charge_calculation
         self.lib = _lib.load()
         self.network = network
         self.N = int(num_envs)
@@ -52,7 +59,8 @@ class StepEngine:
         desc = NetworkDesc(self.n, self._A.shape[0], _np_ptr(self._A), _np_ptr(self._ph),
                            _np_ptr(self._mag), _np_ptr(self._kind))
         flags = (_lib.FLAG_PROJECT_ACTION if project_action else 0) | \
-                (_lib.FLAG_AUTORESET if autoreset else 0)
+                (_lib.FLAG_AUTORESET if autoreset else 0) | \
+                (_lib.FLAG_BATTERY_STEPWISE if charge_calculation == 'stepwise' else 0)
         handle = C.c_void_p()
         check(self.lib.evc_create(C.byref(desc), self.N, self.k, flags, self.device,
                                   self.bank_slots, self.max_sessions, self.moer_days,

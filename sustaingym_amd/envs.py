@@ -107,7 +107,8 @@ class EVChargingEnv(_EnvBase):
     render_mode = None
 
     def __init__(self, data_generator: AbstractTraceGenerator, moer_forecast_steps: int = 36,
-                 project_action_in_env: bool = True, verbose: int = 0, device: int = 0):
+                 project_action_in_env: bool = True, verbose: int = 0, device: int = 0,
+                 charge_calculation: str = 'continuous'):
         assert 1 <= moer_forecast_steps <= 36                                   # env.py:120
         self.data_generator = data_generator
         self.max_timestep = 288                                                  # env.py:124
@@ -121,7 +122,8 @@ class EVChargingEnv(_EnvBase):
         self.action_space = spaces.Box(low=0, high=1.0, shape=(n,), dtype=np.float32)  # env.py:171
         self._engine = StepEngine(self.cn, 1, moer_forecast_steps=k, project_action=project_action_in_env,
                                   autoreset=False, device=device, bank_slots=1,
-                                  max_sessions=MAX_SESSIONS, moer_days=1, debug_outputs=True)
+                                  max_sessions=MAX_SESSIONS, moer_days=1, debug_outputs=True,
+                                  charge_calculation=charge_calculation)
         self._flat = np.zeros(2 * n + k + 2, dtype=np.float32)
         sl = obs_slices(n, k)
         # like the reference (env.py:152-158) the observation arrays are reused buffers
@@ -355,7 +357,7 @@ class EVChargingVectorEnv(_VectorEnvBase):
     def __init__(self, data_generators: Sequence[AbstractTraceGenerator] | Callable[[int], AbstractTraceGenerator],
                  num_envs: int | None = None, moer_forecast_steps: int = 36,
                  project_action_in_env: bool = True, discrete_bins: int = -1, device: int = 0,
-                 output: str = 'numpy', max_sessions: int = 128):
+                 output: str = 'numpy', max_sessions: int = 128, charge_calculation: str = 'continuous'):
         assert output in ('numpy', 'torch')
         self._batched = data_generators if isinstance(data_generators, BatchedGMMTraceGenerator) else None
         self._devgen = data_generators if isinstance(data_generators, DeviceGMMTraceGenerator) else None
@@ -397,7 +399,8 @@ class EVChargingVectorEnv(_VectorEnvBase):
         self._bank_slots = self._ndays if self._realbank is not None else 2 * N
         self._engine = StepEngine(self.cn, N, moer_forecast_steps=k, project_action=project_action_in_env,
                                   autoreset=True, device=device, bank_slots=self._bank_slots,
-                                  max_sessions=max_sessions, moer_days=self._ndays)
+                                  max_sessions=max_sessions, moer_days=self._ndays,
+                                  charge_calculation=charge_calculation)
         from datetime import timedelta
         moer = np.stack([g0.moer_loader.retrieve(self._day0 + timedelta(days=d)) for d in range(self._ndays)])
         self._engine.upload_moer(moer, 0)

@@ -18,19 +18,21 @@ def make_workload(net, num_envs, bank_slots=None, seed=0, moer_days=3, busy=Fals
                 moer_day=moer_day, moer=moer)
 
 
-def make_pair(net, num_envs, workload, project, autoreset=False, stride=1, k=36, debug=True):
+def make_pair(net, num_envs, workload, project, autoreset=False, stride=1, k=36, debug=True,
+              charge_calculation='continuous'):
     """(HIP engine, oracle batch) loaded with the same bank."""
     from sustaingym_amd.engine import StepEngine
     P = len(workload['n_sessions'])
     eng = StepEngine(net, num_envs, moer_forecast_steps=k, project_action=project,
                      autoreset=autoreset, bank_slots=P, max_sessions=workload['sessions'].shape[1],
-                     moer_days=workload['moer'].shape[0], debug_outputs=debug)
+                     moer_days=workload['moer'].shape[0], debug_outputs=debug,
+                     charge_calculation=charge_calculation)
     eng.upload_moer(workload['moer'])
     eng.upload_episodes(workload['n_sessions'], workload['sessions'], workload['requested'],
                         workload['moer_day'])
     eng.set_autoreset_stride(stride)
     onet = ob.OracleNetwork(net)
-    bat = ob.OracleBatch(onet, num_envs, k, project)
+    bat = ob.OracleBatch(onet, num_envs, k, project, charge_calculation)
     bat.set_bank(workload['n_sessions'], workload['sessions'], workload['requested'],
                  workload['moer_day'], workload['moer'], autoreset_stride=stride)
     return eng, bat

@@ -29,8 +29,8 @@ def flat_moer(value=0.3):
     return m
 
 
-def make_env(onet, sessions, requested, project=False, moer=None, k=36):
-    env = ob.OracleEnv(onet, k, project)
+def make_env(onet, sessions, requested, project=False, moer=None, k=36, charge_calculation='continuous'):
+    env = ob.OracleEnv(onet, k, project, charge_calculation)
     s = ob.pack_sessions(*zip(*sessions)) if sessions else np.zeros(0, ob.SESSION_DTYPE)
     obs = env.reset(s, np.array(requested, dtype=np.float64), flat_moer() if moer is None else moer)
     return env, obs
@@ -63,10 +63,10 @@ def test_k1_single_ev_full_rate(onet, net):
     assert abs(32 * A_PERS_TO_KWH - 0.5546666667) < 1e-9
 
 
-def test_k2_taper(onet, net):
-    """K2: remaining 1.0 kWh at soc >= 0.8 with 32 A -> P = 5 kW, rem -> 0.583333."""
+def test_k2_taper_stepwise(onet, net):
+    """K2 (legacy `_charge_stepwise`): remaining 1.0 kWh at soc >= 0.8 with 32 A -> P = 5 kW, rem -> 0.583333."""
     st = 0
-    env, _ = make_env(onet, [(0, 100, 90, st)], [1.0])
+    env, _ = make_env(onet, [(0, 100, 90, st)], [1.0], charge_calculation='stepwise')
     a = np.zeros(net.num_stations, np.float32)
     a[st] = 1.0
     env.step(a)
@@ -74,6 +74,70 @@ def test_k2_taper(onet, net):
     assert abs(res.rates[st] - 5.0 * 1000 / 208) < 1e-9
     rem, _, _ = env.station_state()
     assert abs(rem[st] - (1.0 - 5.0 / 12)) < 1e-12
+
+
+def _one_period(onet, net, requested, amps, charge_calculation='continuous', st=0):
+    """Remaining demand and delivered rate after ONE charging period of a fresh EV at `amps` (AV EVSE)."""
+    env, _ = make_env(onet, [(0, 100, 90, st)], [requested], charge_calculation=charge_calculation)
+    a = np.zeros(net.num_stations, np.float32)
+    a[st] = amps / 32.0
+    env.step(a)                               # EV plugs in after the first charge pass
+    _, res = env.step(a)
+    assert res.pilots[st] == amps
+    rem, _, _ = env.station_state()
+    return rem[st], res.rates[st]
+
+
+def test_k2_continuous_battery(onet, net):
+    """K2' (acnportal's default `_charge`, hand-derived): with kw = 0.208 pilot the ramp-down starts at headroom
+    rem_T = 0.2 kw; 32 A: kw = 6.656, rem_T = 1.3312, kw/12 = 0.554667.
+      * tail (rem <= rem_T): rem' = rem exp(-5/12): 1.0 kWh -> 0.659241 (the legacy model gives 0.583333)
+      * crossing (0 < rem - rem_T < kw/12): 1.5 kWh -> rem_T exp(-(kw/12 - (1.5 - rem_T))/rem_T) = 0.996224
+      * constant-rate (rem - rem_T >= kw/12): 30 kWh -> 30 - 0.554667, delivered rate = pilot
+      * the tail factor does not depend on the pilot: 16 A, rem_T = 0.6656: 0.5 kWh -> 0.5 exp(-5/12)"""
+    e = np.exp(-5.0 / 12.0)
+    assert abs(e - 0.6592406302) < 1e-10
+    rem, amps = _one_period(onet, net, 1.0, 32.0)
+    assert abs(rem - e) < 1e-12
+    assert abs(amps - (1.0 - e) * 12 * 1000 / 208) < 1e-10
+    rem, amps = _one_period(onet, net, 1.5, 32.0)
+    kw, rem_t = 6.656, 1.3312
+    want = rem_t * np.exp(-(kw / 12 - (1.5 - rem_t)) / rem_t)
+    assert abs(want - 0.9962241555) < 1e-9
+    assert abs(rem - want) < 1e-12
+    assert abs(amps - (1.5 - want) * 12 * 1000 / 208) < 1e-10
+    rem, amps = _one_period(onet, net, 30.0, 32.0)
+    assert abs(rem - (30.0 - kw / 12)) < 1e-12 and abs(amps - 32.0) < 1e-11
+    rem, amps = _one_period(onet, net, 0.5, 16.0)
+    assert abs(rem - 0.5 * e) < 1e-12
+    # the two regions meet continuously: just above / below rem_T + kw/12 and rem_T
+    for r0 in (rem_t + kw / 12, rem_t):
+        lo, _ = _one_period(onet, net, r0 - 1e-9, 32.0)
+        hi, _ = _one_period(onet, net, r0 + 1e-9, 32.0)
+        assert abs(hi - lo) < 1e-8
+    # both models agree wherever the battery stays in the constant-rate region
+    for req in (5.0, 30.0, 99.0):
+        assert abs(_one_period(onet, net, req, 32.0)[0] - _one_period(onet, net, req, 32.0, 'stepwise')[0]) < 1e-12
+
+
+def test_k2_continuous_session_never_overshoots(onet, net):
+    """A whole session at full rate under the continuous model: demand decreases monotonically, stays >= 0,
+    energy delivered never exceeds the request, and the EV leaves the observation once below 1e-3 kWh."""
+    st = 0
+    env, _ = make_env(onet, [(0, 200, 190, st)], [4.0])
+    a = np.zeros(net.num_stations, np.float32)
+    a[st] = 1.0
+    env.step(a)
+    last, gone = 4.0, None
+    for i in range(60):
+        obs, res = env.step(a)
+        rem = env.station_state()[0][st]
+        assert 0.0 <= rem <= last + 1e-15 and res.rates[st] >= 0.0
+        last = rem
+        if rem <= 1e-3 and gone is None:
+            gone = i
+            assert obs[st] == 0.0 and obs[net.num_stations + st] == 0.0     # EV.fully_charged -> not active
+    assert gone is not None and gone > 13                                  # the legacy model needs 13 periods
 
 
 def test_k3_rounding(onet, net):

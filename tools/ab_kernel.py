@@ -12,7 +12,8 @@ moer = synthetic_moer(32, seed=7)
 g = torch.Generator(device='cuda'); g.manual_seed(1234)
 ring = [torch.rand((N, n), device='cuda', generator=g) for _ in range(8)]
 for project in (True, False):
-    eng = StepEngine(net, N, project_action=project, autoreset=True, bank_slots=8192, max_sessions=64, moer_days=32)
+    eng = StepEngine(net, N, project_action=project, autoreset=True, bank_slots=8192, max_sessions=64, moer_days=32,
+                     charge_calculation=os.environ.get('EVC_AB_BATTERY', 'continuous'))
     eng.upload_moer(moer); eng.upload_episodes(ns, sess, req, day); eng.reset()
     step, out = eng.make_stepper()
     for i in range(288): step(ring[i % 8].data_ptr())
