@@ -73,6 +73,10 @@ extern "C" {
 #define EVC_ACTION_GREEDY    2   /* no action buffer: device-resident GreedyAlgorithm policy,
                                     a = 1 where observation['demands'] > 0 else 0
                                     (algorithms/evcharging/baselines.py:32-35)                   */
+#define EVC_ACTION_RANDOM    3   /* no action buffer: device-resident RandomAlgorithm policy
+                                    (algorithms/evcharging/baselines.py:38-51): uniform actions
+                                    from a counter-based stream keyed by evc_set_policy_seed;
+                                    bins >= 2 draws DiscreteActionWrapper levels instead        */
 
 /* per-environment status bits (replace the reference's exceptions / pdb) */
 #define EVC_STATUS_OCCUPIED     (1u << 0)  /* plug-in into an occupied EVSE (acnportal StationOccupiedError); session skipped */
@@ -227,6 +231,18 @@ int evc_step(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_
  * BaseAlgorithm.run (algorithms/base.py:63-88). */
 int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
                 int32_t steps, int32_t ring_len, const evc_step_out* out);
+
+/* Seeds the device-resident random policy (EVC_ACTION_RANDOM).  The action of station s of environment
+ * e in period t of its episode number p is a pure function of (seed, env_id_base + e, p, t, s):
+ * Philox4x32-10, key = seed, counter = (t | (s/4) << 16, p, env_id_base + e, 0x504f4c43), word s%4;
+ * continuous a = (w >> 8) * 2^-24, discrete level = (w * bins) >> 32.  env_id_base = global id of this
+ * engine's environment 0 (multi-GPU shards draw disjoint streams).  Replaces RandomAlgorithm's
+ * np.random.default_rng() (baselines.py:42), whose sequential stream cannot be drawn in parallel. */
+int evc_set_policy_seed(evc_engine* e, uint64_t seed, uint32_t env_id_base);
+
+/* Writes the actions EVC_ACTION_RANDOM would apply to the environments in their current state into
+ * actions_dev (float32 [N][n]); evc_step(EVC_ACTION_RANDOM) = this + evc_step(EVC_ACTION_F32). */
+int evc_fill_random_actions(evc_engine* e, int32_t bins, float* actions_dev);
 
 /* Per-agent observations of the multi-agent environment (multiagent_env.py:102-148) for the whole
  * batch: out_dev[N][n][F].  Agent a of environment e receives the flattened observation obs_dev[e]

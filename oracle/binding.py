@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
         L.orc_gen_normal.argtypes = [C.c_double]
         L.orc_generate_episode.restype = i32
         L.orc_generate_episode.argtypes = [C.POINTER(GmmDesc), i32, C.c_uint64, C.c_uint64, i32, vp, vp, vp, vp]
+        L.orc_random_action.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, i32, i32, vp]
         L.bor_create.restype = vp
         L.bor_create.argtypes = [i32] + [C.c_double] * 6
         L.bor_destroy.argtypes = [vp]
@@ -264,6 +265,17 @@ class OracleBatch:
                              _p(out['breakdown']), _p(out['final_obs']), _p(out.get('pilots')),
                              _p(out.get('rates')), _p(out.get('projected')), _p(out['status']))
         return out
+
+
+def random_actions(seed: int, env_ids, episodes, t, n: int, bins: int = 0) -> np.ndarray:
+    """orc_random_action for a batch: float32 [len(env_ids), n]."""
+    env_ids, episodes, t = np.broadcast_arrays(np.asarray(env_ids), np.asarray(episodes), np.asarray(t))
+    out = np.zeros((len(env_ids), n), np.float32)
+    L = lib()
+    for i in range(len(env_ids)):
+        L.orc_random_action(int(seed) & (2 ** 64 - 1), int(env_ids[i]), int(episodes[i]), int(t[i]), n, bins,
+                            out[i].ctypes.data)
+    return out
 
 
 def philox4x32(counter, key) -> np.ndarray:

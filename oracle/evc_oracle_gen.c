@@ -192,3 +192,24 @@ int orc_generate_episode(const orc_gmm* g, int n_stations, uint64_t seed, uint64
     *max_profit = profit;
     return n_out;
 }
+
+/* Device-resident RandomAlgorithm policy (reference: algorithms/evcharging/baselines.py:38-51 draws
+ * rng.random(n) / rng.choice(5, n) from np.random.default_rng(); the engine replaces the sequential
+ * stream by a counter-based one, include/evcharge.h:evc_set_policy_seed).  Action of every station of
+ * global environment `env` in period t of its episode number `episode`:
+ *   Philox4x32-10, key = seed, counter = (t | block << 16, episode, env, 0x504f4c43), block = s / 4,
+ *   word s % 4;  continuous: (w >> 8) * 2^-24;  discrete: level = (w * bins) >> 32, a = level/(bins-1)
+ *   in float32 (wrappers.py:43-45). */
+void orc_random_action(uint64_t seed, uint32_t env, uint32_t episode, uint32_t t, int n, int bins,
+                       float* out) {
+    for (int s = 0; s < n; s++) {
+        uint32_t w[4];
+        orc_philox4x32(t | ((uint32_t)(s / 4) << 16), episode, env, 0x504f4c43u, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), w);
+        const uint32_t x = w[s % 4];
+        if (bins >= 2)
+            out[s] = (float)(uint32_t)(((uint64_t)x * (uint32_t)bins) >> 32) / (float)(bins - 1);
+        else
+            out[s] = (float)(x >> 8) * (1.0f / 16777216.0f);
+    }
+}

@@ -23,7 +23,7 @@ MOER_ROWS, MOER_COLS, EPISODE_STEPS = 289, 37, 288
 FLAG_PROJECT_ACTION = 1 << 0
 FLAG_AUTORESET = 1 << 1
 FLAG_BATTERY_STEPWISE = 1 << 2    # acnportal Linear2StageBattery(charge_calculation='stepwise'), the legacy model
-ACTION_F32, ACTION_DISCRETE, ACTION_GREEDY = 0, 1, 2
+ACTION_F32, ACTION_DISCRETE, ACTION_GREEDY, ACTION_RANDOM = 0, 1, 2, 3
 
 STATUS_OCCUPIED = 1 << 0
 STATUS_PROJ_NOCONV = 1 << 1
@@ -79,6 +79,8 @@ SIGNATURES = {
     'evc_reset': (_i32, [_vp, _vp, _i32, _vp, _vp]),
     'evc_step': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
     'evc_rollout': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(StepOut)]),
+    'evc_set_policy_seed': (_i32, [_vp, C.c_uint64, _u32]),
+    'evc_fill_random_actions': (_i32, [_vp, _i32, _vp]),
     'evc_gather_agent_obs': (_i32, [_vp, _vp, _vp, _vp]),
     'evc_host_register': (_i32, [_vp, C.c_size_t]),
     'evc_host_unregister': (_i32, [_vp]),

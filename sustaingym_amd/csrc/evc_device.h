@@ -289,6 +289,22 @@ struct BitPlanes {
     }
 };
 
+// Philox4x32-10 (Salmon et al., SC'11): the counter-based random stream of the episode generator
+// (evc_gen.h) and of the device-resident random policy (evc_kernels.h).
+struct Philox {
+    unsigned w[4];
+    __device__ __forceinline__ Philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+        for (int round = 0; round < 10; round++) {
+            const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+            const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+            c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // per-station physics
 // ------------------------------------------------------------------------------------------

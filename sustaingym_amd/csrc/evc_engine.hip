@@ -94,6 +94,8 @@ struct evc_engine {
     int step_parity = 0;
     int num_cus = 256;
     int step_grid = 0, solver_grid = 0, quad_grid = 0;
+    unsigned long long policy_seed = 0;   // EVC_ACTION_RANDOM (evc_set_policy_seed)
+    unsigned env_id_base = 0;
     bool compact = false;        // state layout (Params::compact)
     bool use_quad = false;
 };
@@ -238,14 +240,24 @@ void compute_grids(evc_engine* e) {
     e->use_quad = e->P.m <= 16 && fits32 && !(kk && strcmp(kk, "wave") == 0) && !(e->compact && e->P.win_span == 0u);
 }
 
+void launch_random_actions(evc_engine* e, int bins, float* actions_dev) {
+    const size_t total = (size_t)e->P.N * ((e->P.n + 3) / 4);
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(random_actions_kernel, dim3(blocks), dim3(256), 0, e->stream, (const int4*)e->d_scal,
+                       actions_dev, e->P.N, e->P.n, bins, e->policy_seed, e->env_id_base);
+}
+
 int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bins,
                 const evc_step_out* out) {
     if (!out || !out->obs || !out->reward || !out->terminated)
         return fail(EVC_EINVAL, "evc_step: out->obs, out->reward, out->terminated required");
-    if (action_kind != EVC_ACTION_F32 && action_kind != EVC_ACTION_DISCRETE && action_kind != EVC_ACTION_GREEDY)
+    if (action_kind != EVC_ACTION_F32 && action_kind != EVC_ACTION_DISCRETE && action_kind != EVC_ACTION_GREEDY &&
+        action_kind != EVC_ACTION_RANDOM)
         return fail(EVC_EINVAL, "evc_step: unknown action_kind %d", action_kind);
-    if (!actions_dev && action_kind != EVC_ACTION_GREEDY)
+    if (!actions_dev && action_kind != EVC_ACTION_GREEDY && action_kind != EVC_ACTION_RANDOM)
         return fail(EVC_EINVAL, "evc_step: actions required");
+    if (action_kind == EVC_ACTION_RANDOM && bins == 1)
+        return fail(EVC_EINVAL, "evc_step: random discrete actions need bins >= 2 (bins <= 0: continuous)");
     if (action_kind == EVC_ACTION_DISCRETE && bins < 2)
         return fail(EVC_EINVAL, "evc_step: discrete actions need bins >= 2");
     StepIO io;
@@ -260,6 +272,11 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(discretize_kernel, dim3(blocks), dim3(256), 0, e->stream,
                            (const long long*)actions_dev, e->d_act_f32, count, bins);
+        io.actions = e->d_act_f32;
+    }
+    if (action_kind == EVC_ACTION_RANDOM) {
+        if (!e->d_act_f32) HIP_TRY(dmalloc(&e->d_act_f32, (size_t)e->P.N * e->P.n));
+        launch_random_actions(e, bins, e->d_act_f32);
         io.actions = e->d_act_f32;
     }
     // The slow-queue counter is double-buffered: step s appends to counter[s & 1] and the slow
@@ -730,16 +747,33 @@ int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int
                 int32_t steps, int32_t ring_len, const evc_step_out* out) {
     if (!e) return fail(EVC_EINVAL, "null engine");
     if (steps < 1) return fail(EVC_EINVAL, "evc_rollout: steps must be >= 1");
-    if (action_kind != EVC_ACTION_GREEDY && (!actions_dev || ring_len < 1))
+    const bool device_policy = action_kind == EVC_ACTION_GREEDY || action_kind == EVC_ACTION_RANDOM;
+    if (!device_policy && (!actions_dev || ring_len < 1))
         return fail(EVC_EINVAL, "evc_rollout: actions and ring_len >= 1 required");
     if (int rc = bind(e)) return rc;
     const size_t elem = action_kind == EVC_ACTION_DISCRETE ? 8 : 4;
     const size_t stride = (size_t)e->P.N * e->P.n * elem;
     for (int i = 0; i < steps; i++) {
-        const void* a = action_kind == EVC_ACTION_GREEDY
+        const void* a = device_policy
             ? nullptr : (const void*)((const char*)actions_dev + (size_t)(i % ring_len) * stride);
         if (int rc = launch_step(e, a, action_kind, bins, out)) return rc;
     }
+    return EVC_OK;
+}
+
+int evc_set_policy_seed(evc_engine* e, uint64_t seed, uint32_t env_id_base) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    e->policy_seed = seed;
+    e->env_id_base = env_id_base;
+    return EVC_OK;
+}
+
+int evc_fill_random_actions(evc_engine* e, int32_t bins, float* actions_dev) {
+    if (!e || !actions_dev) return fail(EVC_EINVAL, "evc_fill_random_actions: null argument");
+    if (bins == 1) return fail(EVC_EINVAL, "evc_fill_random_actions: discrete actions need bins >= 2");
+    if (int rc = bind(e)) return rc;
+    launch_random_actions(e, bins, actions_dev);
+    HIP_TRY(hipGetLastError());
     return EVC_OK;
 }
 
@@ -779,7 +813,7 @@ int evc_host_unregister(void* ptr) {
 
 int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, int32_t bins,
                   const evc_step_out* oh) {
-    if (!e || !oh || (!actions_host && action_kind != EVC_ACTION_GREEDY))
+    if (!e || !oh || (!actions_host && action_kind != EVC_ACTION_GREEDY && action_kind != EVC_ACTION_RANDOM))
         return fail(EVC_EINVAL, "evc_step_host: null argument");
     if (int rc = bind(e)) return rc;
     if (int rc = ensure_staging(e)) return rc;

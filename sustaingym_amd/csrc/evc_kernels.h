@@ -523,6 +523,38 @@ __global__ __launch_bounds__(256) void discretize_kernel(const long long* in, fl
         out[i] = (float)in[i] / denom;
 }
 
+// Device-resident RandomAlgorithm policy (algorithms/evcharging/baselines.py:38-51): uniform actions for
+// every environment at its CURRENT period, written to the [N][n] float32 action buffer the step kernel
+// reads.  Counter-based (Philox4x32-10, key = 64-bit policy seed), so the action of (environment, episode,
+// period, station) does not depend on launch geometry, sharding or call history:
+//   counter = (t | block << 16, episodes_done, env_id_base + env, 0x504f4c43), block = station / 4,
+//   word j -> station 4 block + j;  continuous: a = (w >> 8) 2^-24 in [0,1);  discrete (bins >= 2):
+//   level = (w bins) >> 32, a = float(level) / float(bins - 1)  (wrappers.py:43-45).
+// oracle/evc_oracle_gen.c:orc_random_action is the scalar C statement of the same rule.
+constexpr unsigned kPolicyTag = 0x504f4c43u;
+__global__ __launch_bounds__(256) void random_actions_kernel(const int4* __restrict__ scal, float* __restrict__ out,
+                                                             int N, int n, int bins, unsigned long long seed,
+                                                             unsigned env_id_base) {
+    const int blocks_per_env = (n + 3) >> 2;
+    const size_t total = (size_t)N * blocks_per_env;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int env = (int)(i / blocks_per_env), block = (int)(i % blocks_per_env);
+        const int t = scal[(size_t)env * 2].x, episodes = scal[(size_t)env * 2 + 1].w;
+        const Philox ph((unsigned)t | ((unsigned)block << 16), (unsigned)episodes, env_id_base + (unsigned)env, kPolicyTag,
+                        (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int s = block * 4 + j;
+            if (s >= n) break;
+            const unsigned w = ph.w[j];
+            float a;
+            if (bins >= 2) a = (float)(unsigned)(((unsigned long long)w * (unsigned)bins) >> 32) / (float)(bins - 1);
+            else a = (float)(w >> 8) * (1.0f / 16777216.0f);
+            out[(size_t)env * n + s] = a;
+        }
+    }
+}
+
 // Per-agent observation gather (multiagent_env.py:102-148), HBM-bound: one workgroup per
 // environment streams n rows of F floats (31.5 kB for Caltech) from two F-float source rows.
 __global__ __launch_bounds__(256) void gather_agent_obs_kernel(const float* __restrict__ obs,

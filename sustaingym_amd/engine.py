@@ -40,6 +40,8 @@ class StepEngine:
         self.charge_calculation = charge_calculation
         self.lib = _lib.load()
         self.network = network
+        if hasattr(network, 'warn_if_provisional'):
+            network.warn_if_provisional()       # e.g. the built-in JPL constraint set (network.py)
         self.N = int(num_envs)
         self.n = network.num_stations
         self.k = int(moer_forecast_steps)
@@ -261,6 +263,8 @@ class StepEngine:
         """``steps`` consecutive steps without returning to Python (``evc_rollout``).
 
         ``policy='greedy'``: device-resident GreedyAlgorithm (baselines.py:22-35), no action buffer.
+        ``policy='random'``: device-resident RandomAlgorithm (baselines.py:38-51) on the counter-based
+        stream of :meth:`set_policy_seed`; ``bins >= 2`` draws DiscreteActionWrapper levels.
         Otherwise ``actions`` is a contiguous CUDA tensor ``[R, N, n]`` (float32, or int64 with
         ``bins``) used as a ring.  Returns the device outputs of the last step plus ``'returns'``
         (sum of rewards per environment over the rollout)."""
@@ -276,6 +280,10 @@ class StepEngine:
         so = self._step_out_struct(out, lambda t: C.c_void_p(t.data_ptr()))
         if policy == 'greedy':
             kind, ptr, ring = _lib.ACTION_GREEDY, None, 1
+        elif policy == 'random':
+            kind, ptr, ring = _lib.ACTION_RANDOM, None, 1
+        elif policy is not None:
+            raise ValueError(f'unknown device policy {policy!r}')
         else:
             assert actions is not None and actions.is_cuda and actions.is_contiguous()
             assert actions.shape[1:] == (self.N, self.n)
@@ -283,6 +291,29 @@ class StepEngine:
             ptr, ring = C.c_void_p(actions.data_ptr()), actions.shape[0]
         check(self.lib.evc_rollout(self.handle, ptr, kind, bins, int(steps), int(ring), C.byref(so)),
               'evc_rollout')
+        return out
+
+    def set_policy_seed(self, seed: int, env_id_base: int = 0) -> None:
+        """Seed of the device-resident random policy; ``env_id_base`` = global id of environment 0."""
+        check(self.lib.evc_set_policy_seed(self.handle, C.c_uint64(int(seed) & (2 ** 64 - 1)), int(env_id_base)),
+              'evc_set_policy_seed')
+
+    def fill_random_actions(self, out=None, bins: int = 0):
+        """The actions ``policy='random'`` would apply now: CUDA float32 ``[N, n]``."""
+        torch = self._torch()
+        self._bind_stream()
+        if out is None:
+            out = torch.empty((self.N, self.n), dtype=torch.float32, device=torch.device('cuda', self.device))
+        check(self.lib.evc_fill_random_actions(self.handle, int(bins), C.c_void_p(out.data_ptr())),
+              'evc_fill_random_actions')
+        return out
+
+    def step_policy(self, policy: str, bins: int = 0):
+        """One step of a device-resident policy (``'greedy'`` / ``'random'``), host buffers."""
+        kind = {'greedy': _lib.ACTION_GREEDY, 'random': _lib.ACTION_RANDOM}[policy]
+        out = self._host_buffers()
+        so = self._step_out_struct(out, _np_ptr)
+        check(self.lib.evc_step_host(self.handle, None, kind, int(bins), C.byref(so)), 'evc_step_host')
         return out
 
     def gather_agent_obs(self, obs, delayed=None, out=None):

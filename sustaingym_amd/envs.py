@@ -351,14 +351,19 @@ class EVChargingVectorEnv(_VectorEnvBase):
     ~10 ns per episode) and only the ``max_profit`` values travel to the host.  A :class:`RealTraceBank`
     keeps every real day of the period resident and walks the days sequentially inside the kernel.
 
-    ``output='numpy'`` (default) returns host arrays (SB3 / RLLib); ``'torch'`` takes and returns
-    device tensors without leaving the GPU."""
+    ``output='numpy'`` (default) returns host arrays (SB3 / RLLib) — copies, unless ``zero_copy=True``
+    hands out the engine's two alternating page-locked buffer sets (valid until the step after the next
+    one; what SB3VecEnv, which copies anyway, and throughput measurements use).  ``'torch'`` takes and
+    returns device tensors without leaving the GPU; those ARE the engine's output buffers and are
+    overwritten by the next step (clone what must be kept)."""
 
     def __init__(self, data_generators: Sequence[AbstractTraceGenerator] | Callable[[int], AbstractTraceGenerator],
                  num_envs: int | None = None, moer_forecast_steps: int = 36,
                  project_action_in_env: bool = True, discrete_bins: int = -1, device: int = 0,
-                 output: str = 'numpy', max_sessions: int = 128, charge_calculation: str = 'continuous'):
+                 output: str = 'numpy', max_sessions: int = 128, charge_calculation: str = 'continuous',
+                 zero_copy: bool = False):
         assert output in ('numpy', 'torch')
+        self.zero_copy = bool(zero_copy)
         self._batched = data_generators if isinstance(data_generators, BatchedGMMTraceGenerator) else None
         self._devgen = data_generators if isinstance(data_generators, DeviceGMMTraceGenerator) else None
         self._realbank = data_generators if isinstance(data_generators, RealTraceBank) else None
@@ -558,8 +563,10 @@ class EVChargingVectorEnv(_VectorEnvBase):
             out = self._engine.step(np.ascontiguousarray(actions), bins=bins)
             term = out['terminated'].astype(bool)
             assert bool(term.all()) == boundary == bool(term.any())
-            # the engine alternates between two sets of page-locked output arrays: what this call returns
-            # stays valid until the step after the next one
+            # the engine alternates between two sets of page-locked output arrays: with zero_copy what this
+            # call returns is only valid until the step after the next one; by default the caller gets copies
+            if not self.zero_copy:
+                out = {key: (val.copy() if key != 'final_obs' or boundary else val) for key, val in out.items()}
             truncated = np.zeros(N, dtype=bool)
         else:
             import torch
@@ -668,7 +675,10 @@ class MultiAgentEVChargingVectorEnv:
         obs, rew, term, trunc, info = self.venv.step(actions)
         flat = self.venv._engine.device_outputs()['obs']
         n = self.num_agents
-        agent_obs = self._agent_obs(flat)
+        # On the step that ends the episodes the kernel has already autoreset: `flat` is the first
+        # observation of the next episodes, and — like MultiAgentEVChargingEnv.reset (init=True) — every
+        # slot of the delay ring restarts from it instead of carrying the finished episode's observations.
+        agent_obs = self._agent_obs(flat, init=self.venv._steps_in_episode == 0)
         rewards = (rew / n).unsqueeze(1).expand(-1, n)
         return agent_obs, rewards, term.unsqueeze(1).expand(-1, n), trunc.unsqueeze(1).expand(-1, n), info
 

@@ -30,9 +30,16 @@ Provenance
 """
 from __future__ import annotations
 
+import json
+import os
+import warnings
 from dataclasses import dataclass, field
 
 import numpy as np
+
+class ProvisionalNetworkWarning(UserWarning):
+    """A network whose constraint set is NOT acnportal's (today: the built-in JPL topology) is in use."""
+
 
 EVSE_AV = 0  # AeroVironment: allowable pilots {0} U {6..32} A, min pilot 6
 EVSE_CC = 1  # ClipperCreek: allowable pilots {0, 8, 16, 24, 32} A, min pilot 8
@@ -83,6 +90,57 @@ class ChargingNetwork:
 
     def station_index(self, station_id: str) -> int:
         return self._idx[station_id]
+
+    # --- exchange with a real acnportal installation ("JPL constraint set") ---
+    @classmethod
+    def from_acnportal(cls, cn, site: str) -> 'ChargingNetwork':
+        """Reads off an ``acnportal.acnsim.ChargingNetwork`` exactly the fields the reference reads
+        (env.py:133-134, 373, 451, 485-493; module docstring).  Run once where acnportal is installed::
+
+            from acnportal.acnsim.network.sites import jpl_acn
+            ChargingNetwork.from_acnportal(jpl_acn(), 'jpl').to_json('jpl_acn.json')
+
+        The result is not provisional: it IS the reference's network."""
+        station_ids = [str(s) for s in cn.station_ids]
+        A = np.asarray(cn.constraint_matrix, dtype=np.float64)
+        phase = np.asarray(cn._phase_angles, dtype=np.float64).reshape(-1)
+        mags = np.asarray(cn.magnitudes, dtype=np.float64).reshape(-1)
+        min_pilot = np.asarray(cn.min_pilot_signals, dtype=np.float64).reshape(-1)
+        if not np.isin(min_pilot, (6.0, 8.0)).all():
+            raise ValueError(f'unsupported EVSE types: min_pilot_signals = {sorted(set(min_pilot.tolist()))} '
+                             '(env.py:373 distinguishes 6 A = AeroVironment from 8 A = ClipperCreek only)')
+        names = [str(c) for c in getattr(cn, 'constraint_index', [f'constraint {i}' for i in range(len(mags))])]
+        voltages = np.asarray(getattr(cn, '_voltages', [208.0])).reshape(-1)
+        return cls(site, station_ids, A, phase, mags, names, np.where(min_pilot == 6.0, EVSE_AV, EVSE_CC),
+                   float(voltages[0]) if len(voltages) else 208.0, provisional=False)
+
+    def to_json(self, path: str) -> None:
+        doc = {'format': 'sustaingym_amd.ChargingNetwork/1', 'site': self.site, 'station_ids': self.station_ids,
+               'constraint_matrix': self.constraint_matrix.tolist(), 'phase_angles': self.phase_angles.tolist(),
+               'magnitudes': self.magnitudes.tolist(), 'constraint_names': self.constraint_names,
+               'evse_kind': self.evse_kind.tolist(), 'voltage': self.voltage, 'provisional': bool(self.provisional)}
+        with open(path, 'w') as f:
+            json.dump(doc, f, indent=1)
+
+    @classmethod
+    def from_json(cls, path: str) -> 'ChargingNetwork':
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get('format') != 'sustaingym_amd.ChargingNetwork/1':
+            raise ValueError(f'{path}: not a sustaingym_amd ChargingNetwork file')
+        return cls(doc['site'], list(doc['station_ids']), np.array(doc['constraint_matrix'], dtype=np.float64),
+                   np.array(doc['phase_angles']), np.array(doc['magnitudes']), list(doc['constraint_names']),
+                   np.array(doc['evse_kind'], dtype=np.uint8), float(doc.get('voltage', 208.0)),
+                   provisional=bool(doc.get('provisional', False)))
+
+    def warn_if_provisional(self) -> None:
+        if self.provisional:
+            warnings.warn(
+                f"network {self.site!r}: this constraint set is a PROVISIONAL stand-in, not acnportal's "
+                f"(the reference takes it from the un-vendored acnportal, utils.py:83-88). Action projection and "
+                f"the excess_charge reward term therefore differ from the reference. Export the real one once with "
+                f"ChargingNetwork.from_acnportal(...).to_json(...) and point {NETWORK_ENV_PREFIX}{self.site.upper()} "
+                f"at it (INTEGRATION.md).", ProvisionalNetworkWarning, stacklevel=3)
 
     def a_tilde(self) -> np.ndarray:
         """Complex constraint matrix of env.py:485-486."""
@@ -185,13 +243,36 @@ def jpl_acn(voltage: float = 208.0) -> ChargingNetwork:
                            voltage, provisional=True)
 
 
+NETWORK_ENV_PREFIX = 'SUSTAINGYM_AMD_NETWORK_'
+_DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
+
+
+def exported_network_path(site: str) -> str | None:
+    """Where an exported acnportal network for ``site`` is looked for: ``$SUSTAINGYM_AMD_NETWORK_<SITE>``,
+    then ``sustaingym_amd/data/<site>_acn.json``."""
+    env = os.environ.get(NETWORK_ENV_PREFIX + site.upper())
+    if env:
+        return env
+    packaged = os.path.join(_DATA_DIR, f'{site}_acn.json')
+    return packaged if os.path.exists(packaged) else None
+
+
 def site_str_to_site(site: str) -> ChargingNetwork:
-    """Reference ``utils.site_str_to_site`` (utils.py:83-88)."""
-    if site == 'caltech':
-        return caltech_acn()
-    if site == 'jpl':
-        return jpl_acn()
-    raise ValueError(f"site must be 'caltech' or 'jpl', got {site!r}")
+    """Reference ``utils.site_str_to_site`` (utils.py:83-88).  A network exported from acnportal
+    (``ChargingNetwork.from_acnportal(...).to_json``) takes precedence over the built-in restatement; its
+    station order must be the one the packaged traces / GMMs are indexed by."""
+    if site not in ('caltech', 'jpl'):
+        raise ValueError(f"site must be 'caltech' or 'jpl', got {site!r}")
+    builtin = caltech_acn() if site == 'caltech' else jpl_acn()
+    path = exported_network_path(site)
+    if path is None:
+        return builtin
+    net = ChargingNetwork.from_json(path)
+    if net.station_ids != builtin.station_ids:
+        raise ValueError(f'{path}: station_ids differ from the order the packaged {site} data is indexed by '
+                         f'(SURVEY.md §8a); refusing to mix them')
+    net.site = site
+    return net
 
 
 def station_groups(net: ChargingNetwork) -> tuple[np.ndarray, np.ndarray]:

@@ -182,52 +182,104 @@ def test_vector_env_autoreset_and_single_env_equivalence():
         e.close()
 
 
-def test_greedy_baseline_host_loop_vs_device_rollout():
-    """GreedyAlgorithm (baselines.py:22-35) three ways on real trace days: (1) the reference-style
-    Python episode loop over EVChargingEnv, (2) the oracle driven by the same policy, (3) the
-    device-resident policy through evc_rollout (whole episode in one C call)."""
-    import torch
-    from sustaingym_amd.algorithms import GreedyAlgorithm, RandomAlgorithm
-    from sustaingym_amd.engine import StepEngine
-    from sustaingym_amd.envs import _pad_table
+def test_greedy_policy_rollout_against_host_loop_and_oracle():
+    """GreedyAlgorithm (baselines.py:22-35) three ways on real trace days: (1) a Python episode loop over
+    EVChargingEnv (what BaseAlgorithm.run does, base.py:63-88), (2) the oracle driven by the same policy,
+    (3) PolicyRollout: one environment per seed, device-resident policy, whole episodes in one evc_rollout."""
+    from sustaingym_amd.rollouts import PolicyRollout
+    seeds = [40, 41, 42]
     gen = RealTraceGenerator('caltech', 'Summer 2019')
     env = EVChargingEnv(gen)
-    res = GreedyAlgorithm(env).run([40, 41])
-    assert len(res['return']) == 2 and res['seed'] == [40, 41]
-    # (2) oracle with the same policy on day 40
+    host_returns, host_info = [], []
+    for seed in seeds:                                    # (1)
+        obs, info = env.reset(seed=seed)
+        ret, done = 0.0, False
+        while not done:
+            obs, r, done, _, info = env.step(np.where(obs['demands'] > 0, 1, 0).astype(np.float32))
+            ret += r
+        host_returns.append(ret)
+        host_info.append({'max_profit': info['max_profit'], **info['reward_breakdown']})
+    # (2) oracle with the same policy on the first seed
     g2 = RealTraceGenerator('caltech', 'Summer 2019')
-    g2.set_seed(40)
-    table = g2.get_event_table()
-    moer = g2.get_moer()
+    g2.set_seed(seeds[0])
+    table, moer = g2.get_event_table(), g2.get_moer()
     orc = ob.OracleEnv(ob.OracleNetwork(env.cn), 36, True)
     o_obs = orc.reset(table.sessions, table.requested, moer)
     ret = 0.0
     for t in range(288):
-        a = np.where(o_obs[:54] > 0, 1, 0).astype(np.float32)
-        o_obs, r = orc.step(a)
+        o_obs, r = orc.step(np.where(o_obs[:54] > 0, 1, 0).astype(np.float32))
         ret += r.reward
-    assert abs(ret - res['return'][0]) <= 1e-9 * max(1.0, abs(ret))
-    assert abs(res['reward_breakdown'][0]['profit'] - r.breakdown[0]) <= 1e-9 * max(1.0, r.breakdown[0])
-    # (3) device-resident greedy over a batch: env 0 = day 40, env 1 = day 41
-    eng = StepEngine(env.cn, 2, project_action=True, bank_slots=2, max_sessions=256, moer_days=2)
-    ns, ss, rr, mm = [], [], [], []
-    for seed in (40, 41):
-        g2.set_seed(seed)
-        tb = g2.get_event_table()
-        s, r_ = _pad_table(tb, 256)
-        ns.append(len(tb)); ss.append(s); rr.append(r_); mm.append(g2.get_moer())
-    eng.upload_moer(np.stack(mm))
-    eng.upload_episodes(ns, np.stack(ss), np.stack(rr), [0, 1])
-    eng.reset()
-    out = eng.rollout(policy='greedy', steps=288)
-    torch.cuda.synchronize()
-    got = out['returns'].cpu().numpy()
-    assert np.allclose(got, res['return'], rtol=1e-9, atol=1e-12)
-    assert out['terminated'].cpu().numpy().all()
-    eng.close()
-    rnd = RandomAlgorithm(env, seed=0).run(1)
-    assert np.isfinite(rnd['return'][0])
+    assert abs(ret - host_returns[0]) <= 1e-9 * max(1.0, abs(ret))
+    assert abs(host_info[0]['profit'] - r.breakdown[0]) <= 1e-9 * max(1.0, r.breakdown[0])
+    # (3) all seeds in one call
+    res = PolicyRollout(RealTraceGenerator('caltech', 'Summer 2019'), 'greedy').run(seeds)
+    assert res['seed'] == seeds
+    assert np.allclose(res['return'], host_returns, rtol=1e-9, atol=1e-12)
+    for i in range(len(seeds)):
+        assert abs(res['max_profit'][i] - host_info[i]['max_profit']) < 1e-12
+        for key in ('profit', 'carbon_cost', 'excess_charge'):
+            assert abs(res['reward_breakdown'][i][key] - host_info[i][key]) <= 1e-9 * max(1.0, abs(host_info[i][key]))
+    frame = PolicyRollout(RealTraceGenerator('caltech', 'Summer 2019'), 'greedy').run_frame(2)
+    assert list(frame.columns) == ['seed', 'return', 'max_profit', 'reward_breakdown', 'status'] and len(frame) == 2
     env.close()
+
+
+@pytest.mark.parametrize('bins', [0, 5])
+def test_random_policy_bit_exact_and_rollout(bins):
+    """EVC_ACTION_RANDOM (baselines.py:38-51 on a counter-based stream): the action rows the device draws are
+    bit-identical to the oracle's C statement of the rule — including after an autoreset (episode counter)
+    and with a sharding offset — and a whole rollout under the device policy equals the oracle stepped with
+    those actions."""
+    import torch
+    from sustaingym_amd.engine import StepEngine
+    from sustaingym_amd.network import caltech_acn
+    from helpers import make_workload
+    net = caltech_acn()
+    N, n, P = 48, net.num_stations, 96
+    wl = make_workload(net, N, bank_slots=P, seed=31)
+    eng = StepEngine(net, N, project_action=True, autoreset=True, bank_slots=P,
+                     max_sessions=wl['sessions'].shape[1], moer_days=wl['moer'].shape[0])
+    eng.upload_moer(wl['moer'])
+    eng.upload_episodes(wl['n_sessions'], wl['sessions'], wl['requested'], wl['moer_day'])
+    eng.set_autoreset_stride(N)
+    eng.set_policy_seed(2024, env_id_base=1000)
+    bat = ob.OracleBatch(ob.OracleNetwork(net), N, 36, True)
+    bat.set_bank(wl['n_sessions'], wl['sessions'], wl['requested'], wl['moer_day'], wl['moer'], autoreset_stride=N)
+    g_obs = eng.reset(host=True).copy()
+    assert np.array_equal(g_obs, bat.reset())
+    ret_o = np.zeros(N)
+    ids = 1000 + np.arange(N)
+    for t in range(288 + 20):                          # crosses an autoreset boundary
+        episode, tt = divmod(t, 288)
+        want = ob.random_actions(2024, ids, episode, tt, n, bins)
+        got = eng.fill_random_actions(bins=bins).cpu().numpy()
+        assert np.array_equal(got, want), f't={t}'
+        assert got.min() >= 0.0 and got.max() <= (1.0 if bins else np.float32(1.0 - 2.0 ** -24))
+        g = eng.step_policy('random', bins=bins)
+        o = bat.step(want, autoreset=True, debug=False)
+        ret_o += o['reward']
+        assert np.array_equal(g['terminated'], o['terminated'])
+        assert np.array_equal(g['obs'][:, n:], o['obs'][:, n:])
+        np.testing.assert_allclose(g['reward'], o['reward'], rtol=1e-9, atol=1e-13)
+    if bins == 0:
+        u = np.concatenate([ob.random_actions(2024, ids, 0, tt, n).ravel() for tt in range(40)])
+        assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+    eng.close()
+    # evc_rollout with the device policy = the same episode returns
+    eng = StepEngine(net, N, project_action=True, bank_slots=P, max_sessions=wl['sessions'].shape[1],
+                     moer_days=wl['moer'].shape[0])
+    eng.upload_moer(wl['moer'])
+    eng.upload_episodes(wl['n_sessions'], wl['sessions'], wl['requested'], wl['moer_day'])
+    eng.set_policy_seed(2024, env_id_base=1000)
+    eng.reset()
+    out = eng.rollout(policy='random', steps=288, bins=bins)
+    torch.cuda.synchronize()
+    bat.reset()
+    ret = np.zeros(N)
+    for tt in range(288):
+        ret += bat.step(ob.random_actions(2024, ids, 0, tt, n, bins), debug=False)['reward']
+    np.testing.assert_allclose(out['returns'].cpu().numpy(), ret, rtol=1e-9, atol=1e-12)
+    eng.close()
 
 
 @pytest.mark.parametrize('delay', [0, 3])

@@ -128,3 +128,91 @@ def test_bench_workload_every_output_against_the_oracle(site):
     met = eng.read_metrics()
     assert met['episodes_finished'] == N and met['envs_with_status'] == 0
     eng.close()
+
+
+def test_config2_4096_caltech_continuous_whole_episode_against_the_oracle(caltech):
+    """BASELINE configs[1] at exactly its size: 4 096 batched Caltech environments, continuous actions,
+    projection on, one whole episode; EVERY environment replayed by the oracle, every output compared
+    (per-station pilots bit-exact, rates / projected actions / rewards to 1e-9)."""
+    from helpers import assert_step_parity, make_pair
+    N, n = 4096, caltech.num_stations
+    wl = make_workload(caltech, N, bank_slots=1024, seed=77, moer_days=8)
+    eng, bat = make_pair(caltech, N, wl, project=True)
+    slots = (np.arange(N) % 1024).astype(np.int32)
+    assert np.array_equal(eng.reset(slots=slots, host=True), bat.reset(slots))
+    rng = np.random.default_rng(5)
+    for t in range(288):
+        a = rng.random((N, n), dtype=np.float32)
+        if t % 9 == 0:
+            a = (a > 0.25).astype(np.float32)
+        assert_step_parity(eng.step(a), bat.step(a), n, tag=f'config 2, step {t + 1}')
+    sc = eng.env_scalars()
+    assert np.all(sc['t'] == 288) and not (sc['status'] & 7).any()
+    eng.close()
+
+
+def _expected_agent_obs(cur, delayed, n):
+    """multiagent_env.py:102-148 with the documented delay semantics, in numpy: agent a of environment e gets
+    the flattened observation in which demands / est_departures of the OTHER agents come from `delayed`,
+    its own entries and the MOER / timestep part from `cur`.  [N, F] x 2 -> [N, n, F]."""
+    N, F = cur.shape
+    out = np.broadcast_to(cur[:, None, :], (N, n, F)).copy()
+    if delayed is not None:
+        out[:, :, :2 * n] = delayed[:, None, :2 * n]
+        idx = np.arange(n)
+        out[:, idx, idx] = cur[:, :n]
+        out[:, idx, n + idx] = cur[:, n:2 * n]
+    return out
+
+
+@pytest.mark.parametrize('delay', [0, 3])
+def test_config5_multiagent_8192x54_against_oracle_observations(delay):
+    """BASELINE configs[4] at its size: 8 192 environments x 54 agents, materialised per-agent observations
+    [8192, 54, 146] (258 MB per step) from the HIP gather kernel + the delay ring of
+    MultiAgentEVChargingVectorEnv, across an autoreset boundary.  Expected tensors are built in numpy
+    from the ORACLE's observations of the same episodes (integers / MOER bitwise, float32 demands to the usual
+    2e-7) and, bitwise, from the history of the engine's own flat observations."""
+    import torch
+    from sustaingym_amd import DeviceGMMTraceGenerator, MultiAgentEVChargingVectorEnv
+    N, n, F = 8192, 54, 146
+    gen = DeviceGMMTraceGenerator('caltech', 'Summer 2021', seed=11)
+    venv = MultiAgentEVChargingVectorEnv(gen, num_envs=N, periods_delay=delay, delay_semantics='documented',
+                                         project_action_in_env=True, materialize=True)
+    obs, _ = venv.reset(seed=11)
+    eng = venv.venv._engine
+    # the same episodes for the oracle: both halves of the double-buffered bank + the period's MOER days
+    ns, sess, req, day, _ = eng.download_episodes(0, 2 * N)
+    from datetime import timedelta
+    g0 = venv.venv.generators[0]
+    moer = np.stack([g0.moer_loader.retrieve(venv.venv._day0 + timedelta(days=d)) for d in range(venv.venv._ndays)])
+    orc = ob.OracleBatch(ob.OracleNetwork(venv.venv.cn), N, 36, True)
+    orc.set_bank(ns, sess, req, day, moer, autoreset_stride=N)
+    o_hist = [orc.reset(np.arange(N, dtype=np.int32))]
+    g_hist = [eng.device_outputs()['obs'].cpu().numpy().copy()]
+    assert np.array_equal(g_hist[0], o_hist[0])
+    assert tuple(obs.shape) == (N, n, F)
+    assert np.array_equal(obs.cpu().numpy(), _expected_agent_obs(g_hist[0], None, n))
+    tgen = torch.Generator(device='cuda')
+    tgen.manual_seed(3)
+    check_at = set(range(1, 7)) | set(range(284, 296)) | set(range(40, 280, 47))
+    for t in range(1, 296):
+        a = torch.rand((N, n), device='cuda', generator=tgen)
+        obs, rew, term, trunc, info = venv.step(a)
+        o = orc.step(a.cpu().numpy(), autoreset=True, debug=False)
+        if t == 288:                                        # autoreset: the histories restart
+            assert o['terminated'].all() and bool(term.all())
+            o_hist, g_hist = [], []
+        o_hist.append(o['obs'])
+        g_hist.append(eng.device_outputs()['obs'].cpu().numpy().copy())
+        np.testing.assert_allclose(rew[:, 0].cpu().numpy(), o['reward'] / n, rtol=1e-9, atol=1e-14)
+        if t not in check_at:
+            continue
+        j = len(o_hist) - 1                                 # steps since the last (auto)reset
+        dl = None if (delay == 0 or j == 0) else max(0, j - delay)
+        got = obs.cpu().numpy()
+        want_g = _expected_agent_obs(g_hist[j], None if dl is None else g_hist[dl], n)
+        assert np.array_equal(got, want_g), f'step {t}: gather kernel / ring vs numpy on the engine observations'
+        want_o = _expected_agent_obs(o_hist[j], None if dl is None else o_hist[dl], n)
+        assert np.array_equal(got[:, :, n:], want_o[:, :, n:]), f'step {t}: est_departures / MOER / timestep'
+        np.testing.assert_allclose(got[:, :, :n], want_o[:, :, :n], rtol=2e-7, atol=0, err_msg=f'step {t}: demands')
+    venv.close()
