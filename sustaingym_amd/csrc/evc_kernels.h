@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void discretize_kernel(const long long* in, fl
 //   counter = (t | block << 16, episodes_done, env_id_base + env, 0x504f4c43), block = station / 4,
 //   word j -> station 4 block + j;  continuous: a = (w >> 8) 2^-24 in [0,1);  discrete (bins >= 2):
 //   level = (w bins) >> 32, a = float(level) / float(bins - 1)  (wrappers.py:43-45).
-// oracle/evc_oracle_gen.c:orc_random_action is the scalar C statement of the same rule.
+// (include/evcharge.h: evc_set_policy_seed states the rule; the tests hold an independent scalar C statement of it.)
 constexpr unsigned kPolicyTag = 0x504f4c43u;
 __global__ __launch_bounds__(256) void random_actions_kernel(const int4* __restrict__ scal, float* __restrict__ out,
                                                              int N, int n, int bins, unsigned long long seed,
