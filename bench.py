@@ -1,18 +1,31 @@
 #!/usr/bin/env python
 """bench.py — env-steps/sec of the batched 54-station EVChargingEnv step() on MI355X.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
-driver launches one rank per GPU with torch.distributed.run.  A "step" is one pass of the hot
-path (EVChargingEnv.step: projection -> pilots -> ACN-Sim charge/event pass -> observation ->
-reward) over one batch of environments with the actions already resident in HBM.  Environments
-are independent, so they shard over ranks with no data-path collective (weak scaling: fixed
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver
+launches one rank per GPU with torch.distributed.run; a plain `python bench.py --gpus N` starts its N
+ranks itself (one process per GPU, RCCL); a launcher world that is not N ranks is refused.  A "step" is
+one pass of the hot path (EVChargingEnv.step: projection -> pilots -> ACN-Sim charge / event pass ->
+observation -> reward) over one batch of environments with the actions already resident in HBM.
+Environments are independent, so they shard over ranks with no data-path collective (weak scaling: fixed
 envs per GPU); only the final metrics are all-gathered.
+
+Steady state: the cost of a step follows the time of day of the simulated episodes (empty network at
+night, busiest in the afternoon).  So that ANY K steps measure the average over a day rather than
+whichever hours they happen to cover, the untimed set-up staggers the episode phases uniformly
+(environment i is i mod 288 periods into its day; `--phase sync` starts all episodes together
+instead, as a freshly reset vector env does).
+
+The JSON line carries, beside the headline: `roofline` (dominant kernel, per-launch HIP events),
+`cpu_baseline` (the oracle's C restatement on the host cores, rank 0 at N = 1), and `secondary` —
+the other regimes of BASELINE.json's configs, each outside the headline's timed region.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,7 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic HBM bytes per env-step, Caltech n=54, k=36
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec peak
+EPISODE = 288
+
+
+# algorithmic HBM bytes per env-step (station-shaped accounting), Caltech n=54, k=36:
 #   read action 4n = 216; read+write station state {remaining f64, dep i16, est i16} 12n*2 = 1296;
 #   event cursor + next event ~32; MOER row (k+1)*4 = 148; write obs (2n+k+2)*4 = 584;
 #   write reward/done/breakdown 8+1+24 = 33   => 2309 B
@@ -30,10 +47,7 @@ def algorithmic_bytes_per_env_step(n: int, k: int) -> int:
     return 4 * n + 12 * n * 2 + 32 + (k + 1) * 4 + (2 * n + k + 2) * 4 + 33
 
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec peak
-
-
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=576)
@@ -41,83 +55,369 @@ def parse_args():
     p.add_argument('--envs-per-gpu', type=int, default=65536)
     p.add_argument('--site', default='caltech', choices=['caltech', 'jpl'])
     p.add_argument('--no-project', action='store_true', help='project_action_in_env=False')
-    p.add_argument('--bank', type=int, default=8192, help='distinct synthetic episodes resident in HBM')
+    p.add_argument('--bank', type=int, default=8192, help='distinct episodes resident in HBM')
     p.add_argument('--ring', type=int, default=8, help='distinct action batches resident in HBM')
+    p.add_argument('--phase', default='stagger', choices=['stagger', 'sync'],
+                   help="'stagger' (default): episode phases spread uniformly over the day, every step costs the "
+                        "day's average; 'sync': all episodes start together")
+    p.add_argument('--battery', default='continuous', choices=['continuous', 'stepwise'],
+                   help="acnportal Linear2StageBattery(charge_calculation=...); 'continuous' is acnportal's default")
     p.add_argument('--busy', action='store_true',
                    help='congested variant of the workload (30-60 long sessions per day); not the headline')
     p.add_argument('--episodes', default='synthetic', choices=['synthetic', 'gmm'],
-                   help="'gmm': the bank is generated on the device from the reference's GMM (Summer 2019) - busier\n"
-                        'days than the synthetic default; not the headline')
+                   help="'gmm': the bank is generated on the device from the reference's GMM (Summer 2019); "
+                        'not the headline (it is one of the secondary records)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
-                   help="process-group backend for --gpus > 1 ('nccl' = RCCL; 'gloo' only to exercise the N > 1\n"
+                   help="process-group backend for --gpus > 1 ('nccl' = RCCL; 'gloo' only to exercise the N > 1 "
                         'logic with several ranks on ONE GPU, see --single-device)')
     p.add_argument('--single-device', action='store_true',
                    help='testing aid: every rank uses cuda:0 (needs --backend gloo)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-secondary', action='store_true', help='skip the secondary records (GMM days, multi-agent, battery)')
     p.add_argument('--cpu-envs', type=int, default=8192)
     p.add_argument('--cpu-steps', type=int, default=96, help='minimum timed steps of the cpu_baseline sample')
     p.add_argument('--kernel-timing-steps', type=int, default=288,
-                   help='steps timed kernel by kernel for the roofline leg (288 = one whole day: the launch\n'
-                        'duration follows the time of day)')
-    return p.parse_args()
+                   help='launches timed one by one (HIP events on the engine stream) for the roofline leg')
+    return p.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# self-spawn: `python bench.py --gpus N` without a launcher
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(n: int) -> int:
+    """Starts n copies of this command, one rank per GPU, and relays rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        sys.stderr.write(f'bench.py: ranks exited with {rcs}\n')
+        return 1
+    sys.stdout.write(out0)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# one EV-charging workload on one GPU
+# ------------------------------------------------------------------------------------------------
+class EvWorkload:
+    """Engine + episode bank + action ring for N environments on `dev`, phases set up as asked."""
+
+    def __init__(self, site, N, dev_index, rank, project=True, episodes='synthetic', bank=8192, ring=8, busy=False,
+                 phase='stagger', battery='continuous', seed_base=1000):
+        import torch
+        from sustaingym_amd.engine import StepEngine
+        from sustaingym_amd.network import site_str_to_site
+        from sustaingym_amd.synthetic import synthetic_episodes, synthetic_moer
+        self.torch = torch
+        self.net = net = site_str_to_site(site)
+        self.site, self.N, self.n, self.k, self.project = site, N, net.num_stations, 36, project
+        self.dev = torch.device('cuda', dev_index)
+        self.P = P = min(bank, max(N, 1))
+        self.moer_days = 32
+        self.moer = synthetic_moer(self.moer_days, seed=7)
+        self.eng = eng = StepEngine(net, N, moer_forecast_steps=self.k, project_action=project, autoreset=True,
+                                    device=dev_index, bank_slots=P, max_sessions=128 if episodes == 'gmm' else 64,
+                                    moer_days=self.moer_days, charge_calculation=battery)
+        eng.upload_moer(self.moer)
+        if episodes == 'gmm':
+            from sustaingym_amd.event_generation import gmm_device_tables
+            eng.upload_gmm(dict(gmm_device_tables(site, 'Summer 2019'), num_days=self.moer_days))
+            eng.generate_episodes(0, P, seed_base + rank, 0)
+            self.bank = eng.download_episodes(0, P)[:4]                     # for the cpu_baseline leg
+        else:
+            kw = dict(min_sessions=30, max_sessions=60, max_arrival=120, min_duration=40, max_duration=160) if busy else {}
+            self.bank = synthetic_episodes(P, self.n, seed=seed_base + rank, stride=64, moer_days=self.moer_days, **kw)
+            eng.upload_episodes(*self.bank)
+        eng.set_autoreset_stride(1)
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(1234 + rank)
+        self.ring = [torch.rand((N, self.n), dtype=torch.float32, device=self.dev, generator=gen) for _ in range(ring)]
+        self.ptrs = [t.data_ptr() for t in self.ring]
+        eng.reset()
+        self.step, self.out = eng.make_stepper()
+        self._i = 0
+        if phase == 'stagger':
+            self._stagger()
+
+    def run(self, steps: int) -> None:
+        ptrs, step = self.ptrs, self.step
+        for _ in range(steps):
+            step(ptrs[self._i % len(ptrs)])
+            self._i += 1
+
+    def _stagger(self) -> None:
+        """Untimed set-up: after 287 steps in which group s (env ids = s mod 288) is reset after step s,
+        environment i is 287 - (i mod 288) periods into its episode — every period of the day is present
+        in every launch from here on (and stays so: all episodes last 288 periods)."""
+        N = self.N
+        for s in range(1, EPISODE):
+            self.run(1)
+            ids = np.arange(s, N, EPISODE, dtype=np.int32)
+            if len(ids):
+                self.eng.reset(env_ids=ids, slots=(ids % self.P).astype(np.int32))
+
+    def time_kernels(self, launches: int) -> dict:
+        """Per-launch begin-to-end durations (ms) of the streaming and the slow kernel (evc_enable_timing)."""
+        eng = self.eng
+        eng.enable_timing(True)
+        main_ms, slow_ms, slow_cnt = [], [], []
+        for _ in range(launches):
+            self.run(1)
+            a, b = eng.last_step_ms()
+            main_ms.append(a)
+            slow_ms.append(b)
+            if self.project:
+                slow_cnt.append(eng.last_slow_count())
+        eng.enable_timing(False)
+        return {'main_ms': np.array(main_ms), 'slow_ms': np.array(slow_ms),
+                'slow_envs': float(np.mean(slow_cnt)) if slow_cnt else 0.0}
+
+    def wall_ms_per_step(self, steps: int) -> float:
+        torch = self.torch
+        torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        self.run(steps)
+        torch.cuda.synchronize(self.dev)
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    def close(self) -> None:
+        self.eng.close()
+
+
+def lookup_traffic(site, N, project, layout):
+    """HBM bytes per launch of the streaming kernel from the PMC passes of tools/profile.sh (profiles/traffic.json:
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md, collected in separate --pmc runs)."""
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        tj = json.load(open(tpath))
+        key = f'{site}_N{N}_project{int(project)}' + ('' if layout == 'dense' else f'_{layout}')
+        return tj.get(key, {}).get('hbm_bytes_per_launch'), tj.get(key, {}).get('source')
+    except Exception:
+        return None, None
+
+
+def roofline_record(w: EvWorkload, timed: dict, bytes_per_env_step: int) -> dict:
+    layout = os.environ.get('EVC_LAYOUT', 'compact')          # engine default (DESIGN.md §3)
+    avg = float(timed['main_ms'].mean())
+    alg = bytes_per_env_step * w.N
+    achieved = alg / (avg * 1e-3) / 1e9
+    traffic, source = lookup_traffic(w.site, w.N, w.project, layout)
+    rec = {'bound': 'hbm', 'kernel': 'evc::step_kernel_cquad' if layout == 'compact' else 'evc::step_kernel_quad',
+           'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
+           'traffic': traffic,
+           # what the kernel really moves (the compact state layout needs fewer bytes than the station-shaped
+           # algorithmic accounting): rate and fraction of peak on the MEASURED bytes
+           'traffic_gbs': round(traffic / (avg * 1e-3) / 1e9, 2) if traffic else None,
+           'frac_traffic': round(traffic / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+           'traffic_over_algorithmic': round(traffic / alg, 4) if traffic else None,
+           'traffic_source': source,
+           'state_layout': layout, 'avg_kernel_ms': round(avg, 5),
+           'kernel_ms_min_max': [round(float(timed['main_ms'].min()), 5), round(float(timed['main_ms'].max()), 5)],
+           'kernel_launches_timed': int(len(timed['main_ms'])),
+           'solver_kernel_ms': round(float(timed['slow_ms'].mean()), 5),
+           'slow_queue_envs_per_step': round(timed['slow_envs'], 1),
+           'algorithmic_bytes_per_launch': alg}
+    return rec
+
+
+def cpu_baseline_record(args, w: EvWorkload) -> dict:
+    """The oracle (scalar C restatement, oracle/) on the host cores: bounded sample of the same workload."""
+    from oracle import binding as ob
+    cn, cs = min(args.cpu_envs, w.N), args.cpu_steps
+    ns, sess, req, day = w.bank
+    bat = ob.OracleBatch(ob.OracleNetwork(w.net), cn, w.k, w.project, args.battery)
+    bat.set_bank(ns, sess, req, day, w.moer, autoreset_stride=1)
+    bat.reset(np.arange(cn, dtype=np.int32) % w.P)
+    try:
+        quota = open('/sys/fs/cgroup/cpu.max').read().split()
+        cgroup_cpus = None if quota[0] == 'max' else round(int(quota[0]) / int(quota[1]), 2)
+    except Exception:
+        cgroup_cpus = None
+    host = {'cpu_count': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)), 'cgroup_cpus': cgroup_cpus,
+            'omp_max_threads': ob.max_threads()}
+    cores = ob.default_threads()        # one thread per CPU this process may really use (cgroup quota)
+    acts = [r[:cn].cpu().numpy() for r in w.ring]
+    # skip the empty early-morning periods so that the sample has plugged-in EVs; their rate sizes the timed
+    # sample to ~3 s of wall time on whatever host this is (bounded: --cpu-steps .. 2304 steps = 8 days)
+    t1 = time.perf_counter()
+    for i in range(96):
+        bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=cores)
+    rate0 = cn * 96 / (time.perf_counter() - t1)
+    cs = int(min(2304, max(cs, 3.0 * rate0 / cn)))
+    t1 = time.perf_counter()
+    for i in range(cs):
+        bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=cores)
+    dt = time.perf_counter() - t1
+    t1 = time.perf_counter()                # the same sample continued on one thread (SURVEY §8d asks for both), ~2 s
+    for i in range(4):
+        bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=1)
+    c1 = int(min(96, max(4, 2.0 / ((time.perf_counter() - t1) / 4))))
+    t1 = time.perf_counter()
+    for i in range(c1):
+        bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=1)
+    dt1 = time.perf_counter() - t1
+    return {'value': round(cn * cs / dt, 1), 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{cn} envs x {cs} steps (from period 97 on, across autoresets) of the same workload, {dt:.1f} s, '
+                      f'oracle/ C restatement ({args.battery} battery), OpenMP over envs with {cores} threads',
+            'single_thread_value': round(cn * c1 / dt1, 1),
+            'single_thread_sample': f'{cn} envs x {c1} steps, {dt1:.1f} s, 1 thread', 'host': host}
+
+
+# ------------------------------------------------------------------------------------------------
+# secondary records: the other regimes BASELINE.json's configs name (rank 0, outside the timed region)
+# ------------------------------------------------------------------------------------------------
+def secondary_gmm(site, dev_index, battery) -> dict:
+    """65 536 environments on days sampled on the device from the reference's GMM (Summer 2019 model):
+    the reference's own episode distribution — busier than the headline's synthetic days, pods and feeders
+    bind around midday, the slow kernel takes part."""
+    w = EvWorkload(site, 65536, dev_index, 0, project=True, episodes='gmm', phase='stagger', battery=battery)
+    w.run(32)
+    wall = w.wall_ms_per_step(EPISODE)
+    timed = w.time_kernels(96)
+    alg = algorithmic_bytes_per_env_step(w.n, w.k)
+    rec = {'workload': f'65536 x {w.n}-station ({site}) on device-generated GMM days, projection on, phases staggered',
+           'ms_per_step': round(wall, 5), 'env_steps_per_s': round(65536 / wall * 1e3, 1),
+           'kernel_us': round(float(timed['main_ms'].mean()) * 1e3, 2),
+           'solver_kernel_us': round(float(timed['slow_ms'].mean()) * 1e3, 2),
+           'slow_queue_envs_per_step': round(timed['slow_envs'], 1),
+           'roofline': {'bound': 'hbm', 'algorithmic_bytes_per_env_step': alg,
+                        'achieved': round(alg * 65536 / (wall * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(alg * 65536 / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        'note': 'on the whole step (streaming + slow kernel), not on one kernel'}}
+    w.close()
+    return rec
+
+
+def secondary_multiagent(dev_index, battery) -> dict:
+    """BASELINE configs[4]: 8 192 environments x 54 agents.  'view' = zero-copy [N, n, F] broadcast of the flat
+    observation (what the reference's multiagent_env.py:114-117 hands out: the same array for every agent);
+    'materialised' = the gather kernel writes all 258 MB of per-agent rows, 'delay3' additionally takes the
+    other agents' entries from the observation 3 periods ago (documented semantics)."""
+    import torch
+    N = 8192
+    w = EvWorkload('caltech', N, dev_index, 0, project=True, phase='stagger', battery=battery)
+    n, F = w.n, 2 * w.n + w.k + 2
+    eng = w.eng
+    w.run(16)
+    wall_view = w.wall_ms_per_step(EPISODE)
+    obs = w.out['obs']
+    buf = torch.empty((N, n, F), dtype=torch.float32, device=w.dev)
+    old = obs.clone()
+    out = {}
+    for name, delayed in (('materialised', None), ('delay3', old)):
+        for _ in range(8):
+            w.run(1)
+            eng.gather_agent_obs(obs, delayed, buf)
+        torch.cuda.synchronize(w.dev)
+        t0 = time.perf_counter()
+        for _ in range(96):
+            w.run(1)
+            eng.gather_agent_obs(obs, delayed, buf)
+        torch.cuda.synchronize(w.dev)
+        wall = (time.perf_counter() - t0) / 96 * 1e3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            eng.gather_agent_obs(obs, delayed, buf)
+        e1.record()
+        torch.cuda.synchronize(w.dev)
+        gms = e0.elapsed_time(e1) / 20
+        bytes_gather = N * n * F * 4 + N * F * 4 * (2 if delayed is not None else 1)
+        out[name] = {'ms_per_step': round(wall, 5), 'agent_steps_per_s': round(N * n / wall * 1e3, 1),
+                     'gather_kernel_us': round(gms * 1e3, 2),
+                     'roofline': {'bound': 'hbm', 'kernel': 'evc::gather_agent_obs_kernel',
+                                  'algorithmic_bytes_per_env_step': n * F * 4,
+                                  'achieved': round(bytes_gather / (gms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                                  'unit': 'GB/s', 'frac': round(bytes_gather / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    rec = {'workload': f'{N} x {n} agents (caltech), synthetic days, projection on',
+           'view': {'ms_per_step': round(wall_view, 5), 'agent_steps_per_s': round(N * n / wall_view * 1e3, 1)}, **out}
+    w.close()
+    return rec
+
+
+def secondary_battery(dev_index) -> dict:
+    """BASELINE configs[3] (one GPU's share, 16 384 of 131 072 environments): the synthetic battery-dispatch
+    step of include/battery_dispatch.h (no reference implementation exists)."""
+    import torch
+    from sustaingym_amd.battery import BatteryDispatchVectorEnv, synthetic_market_traces
+    N, k = 16384, 36
+    env = BatteryDispatchVectorEnv(N, k, bank_slots=1024, device=dev_index, output='torch')
+    env.upload_traces(synthetic_market_traces(1024, k, seed=3))
+    env.reset(np.arange(N) % 1024)
+    dev = torch.device('cuda', dev_index)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    bids = [torch.rand((N, 2 * k), device=dev, generator=g) * 90.0 for _ in range(4)]
+    for i in range(32):
+        env.step(bids[i % 4])
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(200):
+        env.step(bids[i % 4])
+    e1.record()
+    torch.cuda.synchronize(dev)
+    wall = (time.perf_counter() - t0) / 200 * 1e3
+    gpu = e0.elapsed_time(e1) / 200
+    alg = (4 * k + 6) * 4 + 2 * k * 4 + 8 + 1 + 2 * 16          # obs row + bids + reward + done + state r/w
+    env.close()
+    return {'workload': f'{N} battery-dispatch envs (synthetic price-taker step), k={k}',
+            'ms_per_step': round(wall, 5), 'env_steps_per_s': round(N / wall * 1e3, 1), 'gpu_ms_per_step': round(gpu, 5),
+            'roofline': {'bound': 'hbm', 'kernel': 'bat::step_kernel', 'algorithmic_bytes_per_env_step': alg,
+                         'achieved': round(alg * N / (gpu * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(alg * N / (gpu * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         'note': 'launch-latency bound at this size (940 B x 16 384 = 15 MB per launch)'}}
 
 
 def main():
     args = parse_args()
+    from sustaingym_amd.distributed import WorldMismatch, resolve_world
+    try:
+        rank, local_rank, world, must_spawn = resolve_world(args.gpus, os.environ)
+    except WorldMismatch as exc:
+        sys.stderr.write(f'bench.py: {exc}\n')
+        sys.exit(2)
+    if must_spawn:
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.single_device:
+        assert args.backend == 'gloo', '--single-device needs --backend gloo (RCCL wants one GPU per rank)'
+        local_rank = 0
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        sys.stderr.write(f'bench.py: rank {rank} wants cuda:{local_rank} but only {ndev} device(s) are visible\n')
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if args.single_device:
-            assert args.backend == 'gloo', '--single-device needs --backend gloo (RCCL wants one GPU per rank)'
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group('gloo')
-    else:
-        dist = None
-        torch.cuda.set_device(local_rank)
+        assert dist.get_world_size() == world == args.gpus
     dev = torch.device('cuda', local_rank)
     coll_dev = dev if (world == 1 or args.backend == 'nccl') else torch.device('cpu')   # where collectives run
 
-    from sustaingym_amd.distributed import all_gather_metrics, max_over_ranks, metrics_vector
-    from sustaingym_amd.engine import StepEngine
-    from sustaingym_amd.network import site_str_to_site
-    from sustaingym_amd.synthetic import synthetic_episodes, synthetic_moer
+    from sustaingym_amd.distributed import all_gather_vector, max_over_ranks, metrics_vector
 
-    net = site_str_to_site(args.site)
-    n, k = net.num_stations, 36
     N = args.envs_per_gpu
     project = not args.no_project
-    P = min(args.bank, max(N, 1))
-    moer_days = 32
-    busy_kw = dict(min_sessions=30, max_sessions=60, max_arrival=120, min_duration=40, max_duration=160) if args.busy else {}
-    ns, sess, req, day = synthetic_episodes(P, n, seed=1000 + rank, stride=64, moer_days=moer_days, **busy_kw)
-    moer = synthetic_moer(moer_days, seed=7)
-    eng = StepEngine(net, N, moer_forecast_steps=k, project_action=project, autoreset=True,
-                     device=local_rank, bank_slots=P, max_sessions=128 if args.episodes == 'gmm' else 64,
-                     moer_days=moer_days)
-    eng.upload_moer(moer)
-    if args.episodes == 'gmm':
-        from sustaingym_amd.event_generation import gmm_device_tables
-        eng.upload_gmm(dict(gmm_device_tables(args.site, 'Summer 2019'), num_days=moer_days))
-        eng.generate_episodes(0, P, 1000 + rank, 0)
-        ns, sess, req, day, _ = eng.download_episodes(0, P)          # for the cpu_baseline leg
-    else:
-        eng.upload_episodes(ns, sess, req, day)
-    eng.set_autoreset_stride(1)
-    eng.reset()
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    ring = [torch.rand((N, n), dtype=torch.float32, device=dev, generator=gen) for _ in range(args.ring)]
-    ptrs = [t.data_ptr() for t in ring]
-    step, out = eng.make_stepper()
+    w = EvWorkload(args.site, N, local_rank, rank, project=project, episodes=args.episodes, bank=args.bank,
+                   ring=args.ring, busy=args.busy, phase=args.phase, battery=args.battery)
+    n, k = w.n, w.k
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -125,145 +425,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(ptrs[i % len(ptrs)])
+    w.run(args.warmup)
     barrier()
+    steps0 = w.eng.read_metrics()['env_steps']
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(ptrs[i % len(ptrs)])
+    w.run(args.steps)
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, coll_dev)
+    local_elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(local_elapsed, coll_dev)
+    timed_env_steps = w.eng.read_metrics()['env_steps'] - steps0
 
     # ---- metrics all-gather (the only collective of the path; off the step critical path) ----
-    # The accumulators are per running episode (env.py:329-338 zeroes them at reset) and the default
-    # warmup + steps ends exactly on an episode boundary, so play to mid-day before reading them.
-    tail = (144 - (args.warmup + args.steps) % 288) % 288
-    for i in range(tail):
-        step(ptrs[i % len(ptrs)])
-    _, total = all_gather_metrics(metrics_vector(eng.read_metrics()), coll_dev)
+    # With synchronised phases the accumulators are per running episode (env.py:329-338 zeroes them at reset)
+    # and the default warmup + steps ends exactly on a boundary, so play to mid-day before reading them.
+    if args.phase == 'sync':
+        w.run((144 - (args.warmup + args.steps) % EPISODE) % EPISODE)
+    local_vec = np.concatenate([metrics_vector(w.eng.read_metrics()),
+                                [local_elapsed, float(local_rank), float(timed_env_steps)]])
+    per_rank = all_gather_vector(local_vec, coll_dev)
+    total = per_rank[:, :6].sum(axis=0)
 
-    # ---- per-kernel duration with HIP events on the engine's stream (rank 0): start / stop events
-    # attached to each launch (evc_enable_timing), averaged over a whole day of steps ----
-    roofline = None
+    roofline = cpu_baseline = episode_generation = secondary = None
     if rank == 0:
-        eng.enable_timing(True)
-        main_ms, slow_ms, slow_cnt = [], [], []
-        for i in range(args.kernel_timing_steps):
-            step(ptrs[i % len(ptrs)])
-            a, b = eng.last_step_ms()
-            main_ms.append(a)
-            slow_ms.append(b)
-            if project:
-                slow_cnt.append(eng.last_slow_count())
-        eng.enable_timing(False)
-        layout = os.environ.get('EVC_LAYOUT', 'compact')          # engine default
-        avg_main = float(np.mean(main_ms))
-        avg_slow = float(np.mean(slow_ms))
-        bytes_per_launch = algorithmic_bytes_per_env_step(n, k) * N
-        achieved = bytes_per_launch / (avg_main * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f'{args.site}_N{N}_project{int(project)}' + ('' if layout == 'dense' else f'_{layout}')
-                traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
-        roofline = {'bound': 'hbm', 'kernel': 'evc::step_kernel_cquad' if layout == 'compact' else 'evc::step_kernel_quad',
-                    'achieved': round(achieved, 2),
-                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
-                    'traffic': traffic, 'state_layout': layout, 'avg_kernel_ms': round(avg_main, 5),
-                    'kernel_ms_min_max': [round(float(np.min(main_ms)), 5), round(float(np.max(main_ms)), 5)],
-                    'kernel_launches_timed': len(main_ms),
-                    'traffic_gbs': (round(traffic / (avg_main * 1e-3) / 1e9, 2) if traffic else None),
-                    'solver_kernel_ms': round(avg_slow, 5),
-                    'slow_queue_envs_per_step': (round(float(np.mean(slow_cnt)), 1) if slow_cnt else 0.0),
-                    'algorithmic_bytes_per_launch': bytes_per_launch}
-
-    # ---- CPU baseline: the oracle (scalar C restatement) on the host cores, bounded sample ----
-    cpu_baseline = None
+        timed = w.time_kernels(args.kernel_timing_steps)
+        roofline = roofline_record(w, timed, algorithmic_bytes_per_env_step(n, k))
+        roofline['launch_overhead_ms'] = round(elapsed / args.steps * 1e3 - roofline['avg_kernel_ms'], 5)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import binding as ob
-        cn, cs = min(args.cpu_envs, N), args.cpu_steps
-        bat = ob.OracleBatch(ob.OracleNetwork(net), cn, k, project)
-        bat.set_bank(ns, sess, req, day, moer, autoreset_stride=1)
-        bat.reset(np.arange(cn, dtype=np.int32) % P)
-        # one thread per CPU this process may actually use (more threads than the cgroup quota only get
-        # throttled): oracle.binding.default_threads
-        try:
-            quota = open('/sys/fs/cgroup/cpu.max').read().split()
-            cgroup_cpus = None if quota[0] == 'max' else round(int(quota[0]) / int(quota[1]), 2)
-        except Exception:
-            cgroup_cpus = None
-        host = {'cpu_count': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)), 'cgroup_cpus': cgroup_cpus,
-                'omp_max_threads': ob.max_threads()}
-        cores = ob.default_threads()
-        acts = [r[:cn].cpu().numpy() for r in ring]
-        # skip the empty early-morning periods so that the sample has plugged-in EVs; their rate sizes the
-        # timed sample to ~3 s of wall time on whatever host this is (bounded: --cpu-steps .. 2304 steps = 8 days)
-        t1 = time.perf_counter()
-        for i in range(96):
-            bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=cores)
-        rate0 = cn * 96 / (time.perf_counter() - t1)
-        cs = int(min(2304, max(cs, 3.0 * rate0 / cn)))
-        t1 = time.perf_counter()
-        for i in range(cs):
-            bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=cores)
-        dt = time.perf_counter() - t1
-        # the same sample continued on one thread (SURVEY §8d asks for both), ~2 s
-        t1 = time.perf_counter()
-        for i in range(4):
-            bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=1)
-        c1 = int(min(96, max(4, 2.0 / ((time.perf_counter() - t1) / 4))))
-        t1 = time.perf_counter()
-        for i in range(c1):
-            bat.step(acts[i % len(acts)], autoreset=True, debug=False, threads=1)
-        dt1 = time.perf_counter() - t1
-        first = 97
-        cpu_baseline = {'value': round(cn * cs / dt, 1), 'unit': 'env-steps/s', 'cores': cores,
-                        'kind': 'port',
-                        'sample': f'{cn} envs x {cs} steps (from period {first} on, across autoresets) of the same '
-                                  f'workload, {dt:.1f} s, oracle/ C restatement, OpenMP over envs with {cores} threads',
-                        'single_thread_value': round(cn * c1 / dt1, 1),
-                        'single_thread_sample': f'{cn} envs x {c1} steps, {dt1:.1f} s, 1 thread', 'host': host}
-
-    # Reset-path row, reported beside the headline: refill the whole episode bank with
-    # the on-device GMM generator (after the timed region; the bank is not used again).
-    episode_generation = None
+        cpu_baseline = cpu_baseline_record(args, w)
     if rank == 0:
+        # Reset-path row: refill the whole episode bank with the on-device GMM generator
+        # (after the timed region; the bank is not used again).
         from sustaingym_amd.event_generation import gmm_device_tables
-        eng.upload_gmm(dict(gmm_device_tables(args.site, 'Summer 2019'), num_days=moer_days))
+        w.eng.upload_gmm(dict(gmm_device_tables(args.site, 'Summer 2019'), num_days=w.moer_days))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        eng.generate_episodes(0, P, 1, 0)
+        w.eng.generate_episodes(0, w.P, 1, 0)
         e0.record()
         for rep in range(10):
-            eng.generate_episodes(0, P, 1, rep * P)
+            w.eng.generate_episodes(0, w.P, 1, rep * w.P)
         e1.record()
         torch.cuda.synchronize()
         gen_ms = e0.elapsed_time(e1) / 10
-        episode_generation = {'kernel': 'evc::generate_kernel', 'episodes': P, 'ms': round(gen_ms, 4),
-                              'episodes_per_s': round(P / gen_ms * 1e3, 1)}
+        episode_generation = {'kernel': 'evc::generate_kernel', 'episodes': w.P, 'ms': round(gen_ms, 4),
+                              'episodes_per_s': round(w.P / gen_ms * 1e3, 1)}
+    w.close()
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = {}
+        for name, fn in (('gmm_caltech', lambda: secondary_gmm('caltech', local_rank, args.battery)),
+                         ('gmm_jpl', lambda: secondary_gmm('jpl', local_rank, args.battery)),
+                         ('multiagent_8192x54', lambda: secondary_multiagent(local_rank, args.battery)),
+                         ('battery_16384', lambda: secondary_battery(local_rank))):
+            try:
+                secondary[name] = fn()
+            except Exception as exc:          # a secondary record must never cost the headline
+                secondary[name] = {'error': f'{type(exc).__name__}: {exc}'}
 
     if rank == 0:
         value = N * world * args.steps / elapsed
+        tags = (' [congested variant]' if args.busy else '') + (' [GMM episodes]' if args.episodes == 'gmm' else '')
         line = {
             'metric': 'env-steps/sec at 65k batched 54-station EVChargingEnv; 1/2/4/8 MI355X',
             'value': round(value, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 5),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-            'data': 'synthetic' if args.episodes == 'synthetic' else 'synthetic actions / MOER, episodes sampled on the device from the packaged GMM',
-            'config': {'workload': f'{N} batched {n}-station EVChargingEnv ({args.site}) per GPU, continuous '
-                                   f'actions, project_action_in_env={project}, autoreset over a {P}-episode bank' + (' [congested variant]' if args.busy else '') + (' [GMM episodes]' if args.episodes == 'gmm' else ''),
+            'data': 'synthetic' if args.episodes == 'synthetic' else
+                    'synthetic actions / MOER, episodes sampled on the device from the packaged GMM',
+            'config': {'workload': f'{N} batched {n}-station EVChargingEnv ({args.site}) per GPU, continuous actions, '
+                                   f'project_action_in_env={project}, autoreset over a {w.P}-episode bank, '
+                                   f'episode phases {"staggered uniformly over the day" if args.phase == "stagger" else "synchronised"}'
+                                   + tags,
                        'envs_per_gpu': N, 'global_envs': N * world, 'parallelism': f'env-shard x{world}',
-                       'actions': 'U[0,1) float32 resident in HBM'},
+                       'actions': 'U[0,1) float32 resident in HBM', 'battery_model': args.battery,
+                       'phase': args.phase},
+            # proof that `world` ranks stepped: gathered over the process group
+            'ranks_seen': int(per_rank.shape[0]),
+            'per_rank': {'value': [round(N * args.steps / e, 1) for e in per_rank[:, 6]],
+                         'device': [int(d) for d in per_rank[:, 7]],
+                         'env_steps_timed': [int(s) for s in per_rank[:, 8]]},
+            'env_steps_timed': int(per_rank[:, 8].sum()),
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'episode_generation': episode_generation,
-            'episode_metrics': {'at_period': 144, 'profit': float(total[0]), 'carbon_cost': float(total[1]),
+            'episode_metrics': {'profit': float(total[0]), 'carbon_cost': float(total[1]),
                                 'excess_charge': float(total[2]), 'episodes_finished': float(total[4]),
                                 'envs_with_status': float(total[5])},
+            'secondary': secondary,
         }
         print(json.dumps(line))
-    eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,6 +29,46 @@ def shard_seeds(base_seed: int | None, rank: int, world: int, global_envs: int) 
     return [None if base_seed is None else base_seed + i for i in range(lo, hi)]
 
 
+class WorldMismatch(RuntimeError):
+    """The launcher's world (RANK / WORLD_SIZE) contradicts what the caller asked for."""
+
+
+def resolve_world(requested_gpus: int, environ) -> tuple[int, int, int, bool]:
+    """``(rank, local_rank, world, must_spawn)`` for a job asked to run on ``requested_gpus`` GPUs of one node.
+
+    * launched by ``torch.distributed.run`` (WORLD_SIZE set): the world must be exactly ``requested_gpus``
+      — a silent one-GPU run labelled as N GPUs is the failure this guards against;
+    * plain ``python ... --gpus N`` with N > 1: the caller has to start N ranks itself (``must_spawn``);
+    * N = 1: single process."""
+    if requested_gpus < 1:
+        raise WorldMismatch(f'--gpus must be >= 1, got {requested_gpus}')
+    ws = environ.get('WORLD_SIZE')
+    if ws is None:
+        return 0, 0, (requested_gpus if requested_gpus > 1 else 1), requested_gpus > 1
+    world = int(ws)
+    if world != requested_gpus:
+        raise WorldMismatch(f'--gpus {requested_gpus} but the launcher started WORLD_SIZE={world} ranks; '
+                            f'refusing to report a {world}-rank run as {requested_gpus} GPUs')
+    rank = int(environ.get('RANK', '0'))
+    local_rank = int(environ.get('LOCAL_RANK', str(rank)))
+    if not (0 <= rank < world):
+        raise WorldMismatch(f'RANK={rank} outside WORLD_SIZE={world}')
+    return rank, local_rank, world, False
+
+
+def all_gather_vector(local: np.ndarray, device=None) -> np.ndarray:
+    """All-gathers a small float64 vector; returns ``[W, len]`` (identity without a process group)."""
+    import torch
+    import torch.distributed as dist
+    local = np.asarray(local, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()):
+        return local[None, :].copy()
+    t = torch.as_tensor(local, dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu().numpy()
+
+
 def metrics_vector(metrics: dict[str, float]) -> np.ndarray:
     return np.array([metrics[k] for k in METRIC_NAMES], dtype=np.float64)
 

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the built-in JPL constraint set announces itself once per run, not once per engine
+    config.addinivalue_line('filterwarnings', 'once::sustaingym_amd.network.ProvisionalNetworkWarning')
 
 
 @pytest.fixture(scope='session')

@@ -125,3 +125,30 @@ def test_battery_envs_shard_over_two_gloo_ranks():
     expect = _battery_shard_returns(0, global_envs)
     np.testing.assert_allclose(total, expect, rtol=1e-12)
     assert total[3] == 40 * global_envs and per_rank.shape == (2, len(METRIC_NAMES))
+
+
+# ---- bench.py --gpus N: the world that runs must be the world that is reported ---------------------
+
+def test_resolve_world():
+    from sustaingym_amd.distributed import WorldMismatch, resolve_world
+    import pytest
+    assert resolve_world(1, {}) == (0, 0, 1, False)
+    assert resolve_world(8, {}) == (0, 0, 8, True)                       # plain `python bench.py --gpus 8`: spawn
+    assert resolve_world(4, {'WORLD_SIZE': '4', 'RANK': '3', 'LOCAL_RANK': '3'}) == (3, 3, 4, False)
+    assert resolve_world(1, {'WORLD_SIZE': '1', 'RANK': '0'}) == (0, 0, 1, False)
+    for gpus, env in ((8, {'WORLD_SIZE': '1', 'RANK': '0'}), (1, {'WORLD_SIZE': '2', 'RANK': '1'}),
+                      (2, {'WORLD_SIZE': '2', 'RANK': '5'}), (0, {})):
+        with pytest.raises(WorldMismatch):
+            resolve_world(gpus, env)
+
+
+def test_bench_refuses_a_mismatched_world():
+    """`bench.py --gpus 2` inside a 3-rank launcher world must fail loudly (before touching a GPU), not
+    report a run of a different size."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
+                        '--single-device'], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and 'WORLD_SIZE=3' in r.stderr and not r.stdout.strip()
