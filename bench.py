@@ -12,7 +12,7 @@ envs per GPU); only the final metrics are all-gathered.
 Steady state: the cost of a step follows the time of day of the simulated episodes (empty network at
 night, busiest in the afternoon).  So that ANY K steps measure the average over a day rather than
 whichever hours they happen to cover, the untimed set-up staggers the episode phases uniformly
-(environment i is i mod 288 periods into its day; `--phase sync` starts all episodes together
+(the four environments of wavefront q are q mod 288 periods into their day; `--phase sync` starts all episodes together
 instead, as a freshly reset vector env does).
 
 The JSON line carries, beside the headline: `roofline` (dominant kernel, per-launch HIP events),
@@ -100,7 +100,9 @@ def spawn_ranks(n: int) -> int:
     if any(rcs):
         sys.stderr.write(f'bench.py: ranks exited with {rcs}\n')
         return 1
-    sys.stdout.write(out0)
+    for ln in out0.splitlines():            # the process-group backend may chat on stdout; the contract is ONE JSON line
+        if ln.startswith('{') and ln.rstrip().endswith('}'):
+            sys.stdout.write(ln + '\n')
     return 0
 
 
@@ -154,13 +156,17 @@ class EvWorkload:
             self._i += 1
 
     def _stagger(self) -> None:
-        """Untimed set-up: after 287 steps in which group s (env ids = s mod 288) is reset after step s,
-        environment i is 287 - (i mod 288) periods into its episode — every period of the day is present
-        in every launch from here on (and stays so: all episodes last 288 periods)."""
+        """Untimed set-up: after 287 steps in which group s — the quads (4 consecutive environments = one
+        wavefront of the streaming kernel) with quad index = s mod 288 — is reset after step s, the environments
+        of quad q are 287 - (q mod 288) periods into their episodes: every period of the day is present in every
+        launch from here on (and stays so: all episodes last 288 periods), each wavefront's four environments share
+        a phase as they do in a synchronised vector env, and the quads a wavefront visits (stride 512) are spread
+        over the day — so a launch costs the average over a synchronised day."""
         N = self.N
+        quad = np.arange(N, dtype=np.int64) // 4
         for s in range(1, EPISODE):
             self.run(1)
-            ids = np.arange(s, N, EPISODE, dtype=np.int32)
+            ids = np.flatnonzero(quad % EPISODE == s).astype(np.int32)
             if len(ids):
                 self.eng.reset(env_ids=ids, slots=(ids % self.P).astype(np.int32))
 
@@ -278,15 +284,17 @@ def secondary_gmm(site, dev_index, battery) -> dict:
     """65 536 environments on days sampled on the device from the reference's GMM (Summer 2019 model):
     the reference's own episode distribution — busier than the headline's synthetic days, pods and feeders
     bind around midday, the slow kernel takes part."""
-    w = EvWorkload(site, 65536, dev_index, 0, project=True, episodes='gmm', phase='stagger', battery=battery)
-    w.run(32)
-    wall = w.wall_ms_per_step(EPISODE)
-    timed = w.time_kernels(96)
+    w = EvWorkload(site, 65536, dev_index, 0, project=True, episodes='gmm', phase='sync', battery=battery)
+    w.run(EPISODE)                                   # one untimed day; the timed one starts at an episode boundary
+    wall = w.wall_ms_per_step(EPISODE)               # one whole synchronised day (what a vector env plays)
+    timed = w.time_kernels(EPISODE)
     alg = algorithmic_bytes_per_env_step(w.n, w.k)
-    rec = {'workload': f'65536 x {w.n}-station ({site}) on device-generated GMM days, projection on, phases staggered',
+    rec = {'workload': f'65536 x {w.n}-station ({site}) on device-generated GMM days, projection on, synchronised episodes, mean over one whole day',
            'ms_per_step': round(wall, 5), 'env_steps_per_s': round(65536 / wall * 1e3, 1),
            'kernel_us': round(float(timed['main_ms'].mean()) * 1e3, 2),
+           'kernel_us_by_4h': [round(float(x.mean()) * 1e3, 1) for x in np.array_split(timed['main_ms'], 6)],
            'solver_kernel_us': round(float(timed['slow_ms'].mean()) * 1e3, 2),
+           'solver_kernel_us_by_4h': [round(float(x.mean()) * 1e3, 1) for x in np.array_split(timed['slow_ms'], 6)],
            'slow_queue_envs_per_step': round(timed['slow_envs'], 1),
            'roofline': {'bound': 'hbm', 'algorithmic_bytes_per_env_step': alg,
                         'achieved': round(alg * 65536 / (wall * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
