@@ -9,6 +9,8 @@
 #include <cstring>
 #include <vector>
 
+#include "evc_hostcopy.h"
+
 #include "../../include/battery_dispatch.h"
 
 namespace {
@@ -195,12 +197,12 @@ int bat_upload_traces(bat_engine* e, int32_t first, int32_t count, const float* 
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     const size_t T = BAT_TRACE_LEN, Tk = BAT_TRACE_LEN + e->P.k, c = count, f = first;
-    HIP_TRY(hipMemcpy((void*)(e->P.price + f * T), price, c * T * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy((void*)(e->P.load + f * T), load, c * T * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy((void*)(e->P.moer + f * T), moer, c * T * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy((void*)(e->P.load_fc + f * Tk), load_fc, c * Tk * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy((void*)(e->P.moer_fc + f * Tk), moer_fc, c * Tk * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy((void*)(e->P.terminal_price + f), terminal_price, c * 8, hipMemcpyHostToDevice));
+    HIP_TRY(copy_h2d((void*)(e->P.price + f * T), price, c * T * 4, e->stream));
+    HIP_TRY(copy_h2d((void*)(e->P.load + f * T), load, c * T * 4, e->stream));
+    HIP_TRY(copy_h2d((void*)(e->P.moer + f * T), moer, c * T * 4, e->stream));
+    HIP_TRY(copy_h2d((void*)(e->P.load_fc + f * Tk), load_fc, c * Tk * 4, e->stream));
+    HIP_TRY(copy_h2d((void*)(e->P.moer_fc + f * Tk), moer_fc, c * Tk * 4, e->stream));
+    HIP_TRY(copy_h2d((void*)(e->P.terminal_price + f), terminal_price, c * 8, e->stream));
     return 0;
 }
 
@@ -211,7 +213,7 @@ int bat_reset(bat_engine* e, const int32_t* slots, float* obs_dev) {
     if (slots) {
         for (int i = 0; i < e->P.N; i++)
             if (slots[i] < 0 || slots[i] >= e->P.bank_slots) return fail(-1, "bat_reset: slot %d outside the bank", slots[i]);
-        HIP_TRY(hipMemcpyAsync(e->d_slots, slots, sizeof(int) * e->P.N, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(copy_h2d(e->d_slots, slots, sizeof(int) * e->P.N, e->stream));
         dslots = e->d_slots;
     }
     hipLaunchKernelGGL(bat_reset_kernel, dim3((e->P.N + 3) / 4), dim3(256), 0, e->stream, e->P, dslots, obs_dev);
@@ -233,19 +235,19 @@ int bat_reset_host(bat_engine* e, const int32_t* slots, float* obs_host) {
     if (!e || !obs_host) return fail(-1, "bat_reset_host: null argument");
     if (int rc = bat_reset(e, slots, e->d_obs)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(obs_host, e->d_obs, sizeof(float) * (size_t)e->P.N * e->P.F, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(obs_host, e->d_obs, sizeof(float) * (size_t)e->P.N * e->P.F, e->stream));
     return 0;
 }
 
 int bat_step_host(bat_engine* e, const float* bids_host, float* obs_host, double* reward_host, uint8_t* terminated_host) {
     if (!e || !bids_host || !obs_host || !reward_host || !terminated_host) return fail(-1, "bat_step_host: null argument");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemcpyAsync(e->d_bids, bids_host, sizeof(float) * (size_t)e->P.N * 2 * e->P.k, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(copy_h2d(e->d_bids, bids_host, sizeof(float) * (size_t)e->P.N * 2 * e->P.k, e->stream));
     if (int rc = bat_step(e, e->d_bids, e->d_obs, e->d_reward, e->d_term)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(obs_host, e->d_obs, sizeof(float) * (size_t)e->P.N * e->P.F, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(reward_host, e->d_reward, sizeof(double) * e->P.N, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(terminated_host, e->d_term, e->P.N, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(obs_host, e->d_obs, sizeof(float) * (size_t)e->P.N * e->P.F, e->stream));
+    HIP_TRY(copy_d2h(reward_host, e->d_reward, sizeof(double) * e->P.N, e->stream));
+    HIP_TRY(copy_d2h(terminated_host, e->d_term, e->P.N, e->stream));
     return 0;
 }
 
@@ -253,8 +255,8 @@ int bat_get_state(bat_engine* e, double* energy_host, int32_t* t_host) {
     if (!e) return fail(-1, "null engine");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (energy_host) HIP_TRY(hipMemcpy(energy_host, e->P.energy, sizeof(double) * e->P.N, hipMemcpyDeviceToHost));
-    if (t_host) HIP_TRY(hipMemcpy(t_host, e->P.t, sizeof(int) * e->P.N, hipMemcpyDeviceToHost));
+    if (energy_host) HIP_TRY(copy_d2h(energy_host, e->P.energy, sizeof(double) * e->P.N, e->stream));
+    if (t_host) HIP_TRY(copy_d2h(t_host, e->P.t, sizeof(int) * e->P.N, e->stream));
     return 0;
 }
 
@@ -264,7 +266,7 @@ int bat_read_metrics(bat_engine* e, double* out_host) {
     HIP_TRY(hipMemsetAsync(e->d_metrics, 0, 4 * sizeof(double), e->stream));
     hipLaunchKernelGGL(bat_metrics_kernel, dim3(64), dim3(256), 0, e->stream, e->P, e->d_metrics);
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(out_host, e->d_metrics, 4 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(out_host, e->d_metrics, 4 * sizeof(double), e->stream));
     out_host[2] = (double)e->env_steps;
     return 0;
 }

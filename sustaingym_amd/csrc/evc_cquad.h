@@ -16,9 +16,11 @@
 //     fed with the entries' class ids.
 #pragma once
 
+#include <cstddef>
 #include <type_traits>
 
 #include "evc_quad.h"
+#include "evc_solver.h"
 
 namespace evc {
 
@@ -31,19 +33,73 @@ struct alignas(16) StationCell {
 #define EVC_CQUAD_WAVES 4
 #endif
 
-template <bool PROJECT, int WORDS, bool DBG>
+// LDS of one workgroup.  `net` comes first and the per-step images follow it so that, once the workgroup's
+// streaming work is done, the same memory serves as the slow path's SolverLds = {LdsNet net; workspace}
+// (in-kernel queue drain, DRAIN = true).
+constexpr int kDrainListMax = 256;
+struct CquadLds {
+    LdsNet net;
+    union Images {
+        struct {
+            // [wave][row][station] image the entries scatter into and the station lanes read back: observation
+            // fields + delivered amps (summed in station order: the result does not depend on the entry order,
+            // i.e. not on the history of plug-ins, and equals the station-layout kernels' bit for bit); zero
+            // between steps
+            StationCell obs_img[4][4][64];
+            float act_img[4][4][64];    // [wave][row][station] clamped action of this step
+        } s;
+        char solver_workspace[sizeof(SolverLds) - sizeof(LdsNet)];
+    } u;
+    uint4 st_mulw[64];          // per station: 0 / 1 / 65536 multipliers of packed words 0..3
+    uint4 st_mulw_hi[64];       // words 4..7
+    unsigned char st_info[64];  // class id | ClipperCreek << 7
+    int local_count;            // DRAIN: environments this workgroup queued for its own slow path ...
+    int local_list[kDrainListMax];   // ... (the engine enables DRAIN only while a workgroup steps at most that many environments)
+};
+static_assert(offsetof(SolverLds, net) == 0, "SolverLds must start with the network tables");
+static_assert(sizeof(SolverLds) <= offsetof(CquadLds, u) + sizeof(CquadLds::Images), "solver workspace must fit the images");
+
+// The in-kernel drain behind a real call (DRAIN kernels): inlined, the slow path's code and live ranges cost
+// the streaming path 5 us per step; with explicit arguments the caller keeps them alive (and spilled) through
+// the whole streaming loop, 3 us (both measured).  So the callee takes ONE constant — the LDS address of the
+// workgroup's CquadLds — and fetches everything else itself: Params / StepIO straight from the kernel-argument
+// segment (uniform scalar loads; both kernels share the signature (Params, StepIO)), the list from LDS.
+constexpr unsigned kStepIOKernargOffset = (unsigned)((sizeof(Params) + alignof(StepIO) - 1) / alignof(StepIO) * alignof(StepIO));
+constexpr unsigned kExplicitKernargBytes = (kStepIOKernargOffset + (unsigned)sizeof(StepIO) + 7u) & ~7u;
+template <int WORDS>
+__device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
+    // In a callable function only the IMPLICIT-argument pointer is defined: it follows the explicit kernel
+    // arguments (8-byte aligned), so the explicit ones sit right below it.
+    const char* ka = (const char*)__builtin_amdgcn_implicitarg_ptr() - kExplicitKernargBytes;
+    const Params& P = *(const Params*)ka;
+    const StepIO& io = *(const StepIO*)(ka + kStepIOKernargOffset);
+    typedef __attribute__((address_space(3))) CquadLds LdsImage;
+    CquadLds& S = *(CquadLds*)(LdsImage*)(size_t)(unsigned)rfl((int)lds);
+    const int lane = (int)(threadIdx.x & 63u);
+    const int count = rfl(S.local_count);
+    // the slow path's SolverLds image = the workgroup's LDS from `net` on (CquadLds)
+    for (int i = 0; i < count; i++) solve_env<WORDS>(P, io, *reinterpret_cast<SolverLds*>(&S), lane, rfl(S.local_list[i]));
+}
+
+// DRAIN: no slow kernel is launched after this one.  Each workgroup keeps the environments whose projection
+// needs the iterative solver in a list of its own (LDS) and, once its streaming work is done, solves them itself
+// (wave 0, one after the other, on the LDS the per-step images no longer need).  No grid-wide hand-off, no
+// global queue: a dependent — almost always empty — launch costs ~2 us per step, a grid-wide "last workgroup
+// drains" scheme 4 us (its ticket needs every store of the launch acknowledged first; both measured), this
+// one s_barrier.  On congested steps the solves of different workgroups run side by side like the slow
+// kernel's; only several queued environments inside ONE workgroup serialise (the engine falls back to the
+// slow kernel once a step queues more than a few dozen, evc_engine.hip "drain mode").
+template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false>
 __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cquad(Params P, StepIO io) {
-    __shared__ LdsNet net;
-    __shared__ uint4 st_mulw[64];          // per station: 0 / 1 / 65536 multipliers of packed words 0..3
-    __shared__ uint4 st_mulw_hi[64];       // words 4..7
-    __shared__ unsigned char st_info[64];  // class id | ClipperCreek << 7
-    // [wave][row][station] image the entries scatter into and the station lanes read back: observation
-    // fields + delivered amps (summed in station order: the result does not depend on the entry order,
-    // i.e. not on the history of plug-ins, and equals the station-layout kernels' bit for bit); zero
-    // between steps
-    __shared__ StationCell obs_img[4][4][64];
-    __shared__ float act_img[4][4][64];    // [wave][row][station] clamped action of this step
-    __shared__ double dbg_img[DBG ? 4 : 1][4][64];
+    static_assert(!DRAIN || (PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");
+    __shared__ CquadLds S;
+    __shared__ double dbg_img[DBG ? 4 : 1][4][64];     // unused (and dropped) in the lean kernels
+    LdsNet& net = S.net;
+    auto& st_mulw = S.st_mulw;
+    auto& st_mulw_hi = S.st_mulw_hi;
+    auto& st_info = S.st_info;
+    auto& obs_img = S.u.s.obs_img;
+    auto& act_img = S.u.s.act_img;
 
     const unsigned tid = threadIdx.x, lane = tid & 63u, q = lane & 15u, row = lane >> 4, wv = tid >> 6;
     const unsigned n = (unsigned)P.n, F = (unsigned)P.F;
@@ -102,6 +158,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
     // a wave runs only four iterations at N = 65 536, so the prologue is a visible share of the launch.
     QuadRaw nxt = issue(walk.first);
 
+    if (DRAIN && tid == 0u) {
+        S.local_count = 0;
+        // the other control block still holds the PREVIOUS step's total (its launch is complete): report it to
+        // the host (drain mode decision) and clear it for the next step
+        if (blockIdx.x == 0u) queue_begin_drain(P, P.slow_count_next[0]);
+    }
     if (tid < 64u) {
         const unsigned s = tid;
         const bool valid = s < n;
@@ -289,7 +351,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
                     anyviol = anyviol && !(fill && !still);
                 }
                 const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel
-                if (queue_me && q == 0u) P.slow_list[atomicAdd(P.slow_count, 1)] = (int)env;
+                if (queue_me && q == 0u) {
+                    if (DRAIN) {
+                        S.local_list[atomicAdd(&S.local_count, 1) & (kDrainListMax - 1)] = (int)env;
+                        __hip_atomic_fetch_add(P.slow_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // diagnostics only
+                    } else {
+                        queue_push(P, (int)env);
+                    }
+                }
                 live = live && !queue_me;                 // queued rows write nothing here
                 pilots_screened = pilots_screened && !undecided;
             }
@@ -566,6 +635,16 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             body(std::integral_constant<int, 1>{});
         }
         lds_sync();
+    }
+
+    if (DRAIN) {
+        __syncthreads();                       // every wave's queue entries are in the list; the images are free
+        const int count = S.local_count;
+        if (__builtin_expect(count != 0, 0) && wv == 0u) {
+#ifndef EVC_ABL_DRAIN_NO_SOLVE      /* ablation builds only: the tail's own cost without the slow path's code */
+            drain_local_list<WORDS>((unsigned)(size_t)(__attribute__((address_space(3))) void*)&S);
+#endif
+        }
     }
 }
 

@@ -119,9 +119,10 @@ struct Params {
     unsigned win_span;
     unsigned off_rem, off_de, off_scal, off_acc, off_sess, off_req, off_hist, off_moer, off_ts;
     // slow-path queue (environments whose projection needs the iterative solver)
-    int* slow_count;               // counter this step appends to
-    int* slow_count_next;          // counter the slow kernel clears for the next step
+    int* slow_count;               // control block {count, ticket} this step appends to
+    int* slow_count_next;          // control block the drainer clears for the next step
     int* slow_list;                // [N]
+    int* host_qlen;                // page-locked host word (device address): queue length of this step, for the engine's drain mode
 };
 
 struct StepIO {

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <vector>
 
+#include "evc_hostcopy.h"
+
 #include "evc_solver.h"
 #include "evc_quad.h"
 #include "evc_cquad.h"
@@ -49,6 +51,10 @@ hipError_t dmalloc(T** p, size_t count) {
 }  // namespace
 
 constexpr bool kDefaultCompact = true;
+constexpr int kQlenRing = 64;
+constexpr int kDrainMaxQueue = 32;      // in-kernel drain while the recent per-step totals stay at or below this ...
+constexpr int kDrainResume = 12;        // ... and, once the slow kernel took over, until they are back at or below this
+constexpr int kQlenWindow = 12;         // ring entries (steps) a decision looks at
 
 struct evc_engine {
     int device = 0;
@@ -68,8 +74,20 @@ struct evc_engine {
     double* d_moer_hist = nullptr;
     float* d_moer_obs = nullptr;
     NetTables* d_tables = nullptr;
-    int* d_slow_count = nullptr;
+    int* d_slow_count = nullptr;  // [2]: queue length per step parity
     int* d_slow_list = nullptr;
+    // Drain mode (who solves what the streaming kernel queues): normally every workgroup of the lean compact
+    // streaming kernel solves the environments it queued itself and NO slow kernel is launched (saves the ~2 us
+    // an almost always empty dependent launch costs per step; solves of different workgroups run side by side).
+    // Once steps queue more than a few dozen environments — several per workgroup would serialise — the slow
+    // kernel takes over (one workgroup per queued environment) until the queues are short again.  The decision
+    // reads the per-step totals the kernels report into a page-locked ring: stale by however far the host runs
+    // ahead, which only costs speed, never correctness — either drainer finishes every queued step.
+    int* h_qlen = nullptr;        // [kQlenRing] host view
+    int* d_qlen = nullptr;        // device address of the same memory
+    unsigned long long step_index = 0;
+    bool solver_mode = false;
+    int drain_override = -1;      // EVC_DRAIN=0/1 forces a mode (measurements)
     int* d_idbuf = nullptr;       // reset ids/slots staging [2N]
     double* d_metrics = nullptr;  // [8]
     double* d_maxprofit = nullptr;  // [bank_slots] env.py:422-429 of the episode in each slot
@@ -117,6 +135,7 @@ void free_all(evc_engine* e) {
         if (p) (void)hipFree(p);
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->h_qlen) (void)hipHostFree(e->h_qlen);
 }
 
 // Station classes: identical (constraint column, phase angle).  Every constraint depends on a
@@ -279,17 +298,29 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         launch_random_actions(e, bins, e->d_act_f32);
         io.actions = e->d_act_f32;
     }
-    // The slow-queue counter is double-buffered: step s appends to counter[s & 1] and the slow
-    // kernel of step s clears counter[(s + 1) & 1] for the next step (no per-step memset kernel).
+    // The slow-queue counter is double-buffered: step s counts in block[s & 1] and whoever drains step s
+    // clears block[(s + 1) & 1] for the next step (no per-step memset kernel).
     e->P.slow_count = e->d_slow_count + (e->step_parity & 1);
     e->P.slow_count_next = e->d_slow_count + ((e->step_parity + 1) & 1);
     e->step_parity ^= 1;
+    e->P.host_qlen = e->d_qlen ? e->d_qlen + (e->step_index % kQlenRing) : nullptr;
     const int words = (e->P.G + 1) / 2;
     const bool dbg = out->pilots || out->rates || out->projected || out->returns ||
                      action_kind == EVC_ACTION_GREEDY;
-#ifndef EVC_ABL_NO_SOLVER
-#define EVC_ABL_NO_SOLVER 0   /* ablation builds only (tools/build_variant.sh): timing without the slow kernel */
-#endif
+    // drain mode (see evc_engine): the lean compact streaming kernel can drain short queues itself
+    bool drain = false;
+    if (e->P.project && e->use_quad && e->compact && !dbg && e->h_qlen) {
+        int recent = 0;                                  // longest queue among the last kQlenWindow reports
+        for (int i = 1; i <= kQlenWindow; i++) {
+            const int v = ((volatile int*)e->h_qlen)[(e->step_index + kQlenRing - i) % kQlenRing];
+            if (v > recent) recent = v;
+        }
+        e->solver_mode = e->solver_mode ? recent > kDrainResume : recent > kDrainMaxQueue;
+        drain = !e->solver_mode;
+        const long long quads_per_wave = (((long long)e->P.N + 3) / 4 + 4LL * e->quad_grid - 1) / (4LL * e->quad_grid);
+        if (quads_per_wave * 16 > kDrainListMax) drain = false;        // a workgroup's list must hold every env it steps
+        if (e->drain_override >= 0) drain = e->drain_override != 0;
+    }
     // With timing on, the two kernels carry their own start / stop events (hipExtLaunchKernel: the
     // events read the dispatch packet's begin / end timestamps, i.e. the duration a kernel trace
     // reports, without the gaps between stream operations).
@@ -301,12 +332,13 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, e->stream, e->P, io);
     };
     bool solver_ran = false;
-#define EVC_LAUNCH_(KDBG, KFAST, KPLAIN, GRID, W)                                                   \
+#define EVC_LAUNCH_(KDBG, KFAST, KDRAIN, KPLAIN, GRID, W)                                           \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \
             if (dbg) launch(KDBG, GRID, 256, 0);                                                   \
+            else if (drain) launch(KDRAIN, GRID, 256, 0);                                          \
             else launch(KFAST, GRID, 256, 0);                                                      \
-            if (!EVC_ABL_NO_SOLVER) {                                                              \
+            if (!drain) {                                                                          \
                 launch(solver_step_kernel<W>, e->solver_grid, 64, 1);                              \
                 solver_ran = true;                                                                 \
             }                                                                                      \
@@ -316,12 +348,14 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         break;
 #define EVC_LAUNCH_QUAD(W)                                                                          \
     EVC_LAUNCH_((step_kernel_quad<true, W, true>), (step_kernel_quad<true, W, false>),             \
+                (step_kernel_quad<true, W, false>),                                                \
                 (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, W)
 #define EVC_LAUNCH_CQUAD(W)                                                                         \
     EVC_LAUNCH_((step_kernel_cquad<true, W, true>), (step_kernel_cquad<true, W, false>),           \
+                (step_kernel_cquad<true, W, false, true>),                                         \
                 (dbg ? step_kernel_cquad<false, W, true> : step_kernel_cquad<false, W, false>), e->quad_grid, W)
 #define EVC_LAUNCH_WAVE(W)                                                                          \
-    EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, W)
+    EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, W)
 #define EVC_LAUNCH_ALL(L)                                                                           \
     switch (words) {                                                                               \
         L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8)                                                    \
@@ -345,6 +379,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     }
     HIP_TRY(hipGetLastError());
     e->env_steps += (unsigned long long)e->P.N;
+    e->step_index++;
     return EVC_OK;
 }
 
@@ -471,7 +506,8 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(hipMemset(e->d_moer_hist, 0, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS));
     A(hipMemset(e->d_moer_obs, 0, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
     A(hipMemset(e->d_slow_count, 0, 2 * sizeof(int)));
-    A(hipMemcpy(e->d_tables, &T, sizeof(T), hipMemcpyHostToDevice));
+    A(hipMemset(e->d_slow_list, 0xff, sizeof(int) * N));
+    A(copy_h2d(e->d_tables, &T, sizeof(T), e->stream));
     for (auto& ev : e->ev) A(hipEventCreate(&ev));
     if (err != hipSuccess) {
         free_all(e);
@@ -485,7 +521,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
             init[2 * i] = make_int4(EVC_EPISODE_STEPS, 0, 0, 0);
             init[2 * i + 1] = make_int4(0, kNoArrival, 0, 0);
         }
-        A(hipMemcpy(e->d_scal, init.data(), sizeof(int4) * N * 2, hipMemcpyHostToDevice));
+        A(copy_h2d(e->d_scal, init.data(), sizeof(int4) * N * 2, e->stream));
     }
     P.rem = e->d_rem; P.depest = e->d_depest; P.scal = e->d_scal; P.acc = e->d_acc;
     P.sessions = e->d_sessions; P.requested = e->d_requested; P.n_sessions = e->d_nsess;
@@ -512,6 +548,14 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
         for (const Arr& a : arrs) *a.off = (unsigned)((uintptr_t)a.p - lo);
     }
     compute_grids(e);
+    // queue lengths reported to the host (drain mode); without it the slow kernel simply always runs
+    if (hipHostMalloc((void**)&e->h_qlen, sizeof(int) * kQlenRing, hipHostMallocMapped) == hipSuccess) {
+        memset(e->h_qlen, 0, sizeof(int) * kQlenRing);
+        if (hipHostGetDevicePointer((void**)&e->d_qlen, e->h_qlen, 0) != hipSuccess) e->d_qlen = nullptr;
+    } else {
+        e->h_qlen = nullptr;
+    }
+    if (const char* s = getenv("EVC_DRAIN")) e->drain_override = atoi(s) != 0 ? 1 : 0;
     *out = e;
     return EVC_OK;
 }
@@ -557,10 +601,8 @@ int evc_upload_moer(evc_engine* e, int32_t first_day, int32_t num_days, const do
             obs[r * EVC_MOER_COLS + c] = (float)moer[r * EVC_MOER_COLS + c];
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(e->d_moer_hist + (size_t)first_day * EVC_MOER_ROWS, hist.data(),
-                      sizeof(double) * rows, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_moer_obs + (size_t)first_day * EVC_MOER_ROWS * EVC_MOER_COLS, obs.data(),
-                      sizeof(float) * rows * EVC_MOER_COLS, hipMemcpyHostToDevice));
+    HIP_TRY(copy_h2d(e->d_moer_hist + (size_t)first_day * EVC_MOER_ROWS, hist.data(), sizeof(double) * rows, e->stream));
+    HIP_TRY(copy_h2d(e->d_moer_obs + (size_t)first_day * EVC_MOER_ROWS * EVC_MOER_COLS, obs.data(), sizeof(float) * rows * EVC_MOER_COLS, e->stream));
     return EVC_OK;
 }
 
@@ -605,13 +647,11 @@ int evc_upload_episodes(evc_engine* e, int32_t first_slot, int32_t count, int32_
     }
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(e->d_sessions + (size_t)first_slot * P.max_sessions, s.data(),
-                      sizeof(evc_session) * s.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_requested + (size_t)first_slot * P.max_sessions, rq.data(),
-                      sizeof(double) * rq.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_nsess + first_slot, n_sessions, sizeof(int) * count, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_slot_moer + first_slot, moer_day, sizeof(int) * count, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_maxprofit + first_slot, profit.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    HIP_TRY(copy_h2d(e->d_sessions + (size_t)first_slot * P.max_sessions, s.data(), sizeof(evc_session) * s.size(), e->stream));
+    HIP_TRY(copy_h2d(e->d_requested + (size_t)first_slot * P.max_sessions, rq.data(), sizeof(double) * rq.size(), e->stream));
+    HIP_TRY(copy_h2d(e->d_nsess + first_slot, n_sessions, sizeof(int) * count, e->stream));
+    HIP_TRY(copy_h2d(e->d_slot_moer + first_slot, moer_day, sizeof(int) * count, e->stream));
+    HIP_TRY(copy_h2d(e->d_maxprofit + first_slot, profit.data(), sizeof(double) * count, e->stream));
     return EVC_OK;
 }
 
@@ -647,7 +687,7 @@ int evc_upload_gmm(evc_engine* e, const evc_gmm_desc* g) {
     if (int rc = bind(e)) return rc;
     if (!e->d_gen) HIP_TRY(hipMalloc(&e->d_gen, sizeof(GenTables)));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(e->d_gen, &T, sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(copy_h2d(e->d_gen, &T, sizeof(T), e->stream));
     return EVC_OK;
 }
 
@@ -681,25 +721,26 @@ int evc_download_episodes(evc_engine* e, int32_t first_slot, int32_t count, int3
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     const size_t S = (size_t)P.max_sessions;
-    if (n_sessions) HIP_TRY(hipMemcpy(n_sessions, e->d_nsess + first_slot, sizeof(int) * count, hipMemcpyDeviceToHost));
-    if (moer_day) HIP_TRY(hipMemcpy(moer_day, e->d_slot_moer + first_slot, sizeof(int) * count, hipMemcpyDeviceToHost));
-    if (max_profit) HIP_TRY(hipMemcpy(max_profit, e->d_maxprofit + first_slot, sizeof(double) * count, hipMemcpyDeviceToHost));
-    // rows of the bank are contiguous when the caller's stride equals max_sessions (the usual case): one
-    // plain copy; a pitched copy only for wider host rows
-    if (sessions) {
-        if ((size_t)stride == S)
-            HIP_TRY(hipMemcpy(sessions, e->d_sessions + first_slot * S, sizeof(evc_session) * S * count, hipMemcpyDeviceToHost));
-        else
-            HIP_TRY(hipMemcpy2D(sessions, sizeof(evc_session) * (size_t)stride, e->d_sessions + first_slot * S,
-                                sizeof(evc_session) * S, sizeof(evc_session) * S, count, hipMemcpyDeviceToHost));
-    }
-    if (requested) {
-        if ((size_t)stride == S)
-            HIP_TRY(hipMemcpy(requested, e->d_requested + first_slot * S, sizeof(double) * S * count, hipMemcpyDeviceToHost));
-        else
-            HIP_TRY(hipMemcpy2D(requested, sizeof(double) * (size_t)stride, e->d_requested + first_slot * S,
-                                sizeof(double) * S, sizeof(double) * S, count, hipMemcpyDeviceToHost));
-    }
+    if (n_sessions) HIP_TRY(copy_d2h(n_sessions, e->d_nsess + first_slot, sizeof(int) * count, e->stream));
+    if (moer_day) HIP_TRY(copy_d2h(moer_day, e->d_slot_moer + first_slot, sizeof(int) * count, e->stream));
+    if (max_profit) HIP_TRY(copy_d2h(max_profit, e->d_maxprofit + first_slot, sizeof(double) * count, e->stream));
+    // rows of the bank are contiguous when the caller's stride equals max_sessions (the usual case): one copy;
+    // wider host rows: contiguous copy into a scratch vector, rows spread on the CPU
+    auto rows_out = [&](void* dst, const void* src_dev, size_t elem) -> int {
+        if ((size_t)stride == S) {
+            HIP_TRY(copy_d2h(dst, src_dev, elem * S * count, e->stream));
+            return EVC_OK;
+        }
+        std::vector<char> tmp(elem * S * count);
+        HIP_TRY(copy_d2h(tmp.data(), src_dev, tmp.size(), e->stream));
+        for (int i = 0; i < count; i++)
+            memcpy((char*)dst + (size_t)i * stride * elem, tmp.data() + (size_t)i * S * elem, elem * S);
+        return EVC_OK;
+    };
+    if (sessions)
+        if (int rc = rows_out(sessions, e->d_sessions + first_slot * S, sizeof(evc_session))) return rc;
+    if (requested)
+        if (int rc = rows_out(requested, e->d_requested + first_slot * S, sizeof(double))) return rc;
     return EVC_OK;
 }
 
@@ -720,13 +761,13 @@ int evc_reset(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_
     if (env_ids) {
         for (int i = 0; i < count; i++)
             if (env_ids[i] < 0 || env_ids[i] >= P.N) return fail(EVC_EINVAL, "evc_reset: env id %d", env_ids[i]);
-        HIP_TRY(hipMemcpyAsync(e->d_idbuf, env_ids, sizeof(int) * count, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(copy_h2d(e->d_idbuf, env_ids, sizeof(int) * count, e->stream));
         d_ids = e->d_idbuf;
     }
     if (slots) {
         for (int i = 0; i < count; i++)
             if (slots[i] < 0 || slots[i] >= P.bank_slots) return fail(EVC_EINVAL, "evc_reset: slot %d", slots[i]);
-        HIP_TRY(hipMemcpyAsync(e->d_idbuf + P.N, slots, sizeof(int) * count, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(copy_h2d(e->d_idbuf + P.N, slots, sizeof(int) * count, e->stream));
         d_slots = e->d_idbuf + P.N;
     }
     hipLaunchKernelGGL(reset_kernel, dim3((count + 3) / 4), dim3(256), 0, e->stream, e->P, d_ids,
@@ -796,7 +837,7 @@ int evc_reset_host(evc_engine* e, const int32_t* env_ids, int32_t count, const i
     if (int rc = evc_reset(e, env_ids, count, slots, e->d_obs)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (obs_host)
-        HIP_TRY(hipMemcpy(obs_host, e->d_obs, sizeof(float) * (size_t)e->P.N * e->P.F, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_d2h(obs_host, e->d_obs, sizeof(float) * (size_t)e->P.N * e->P.F, e->stream));
     return EVC_OK;
 }
 
@@ -820,7 +861,7 @@ int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, 
     const size_t N = e->P.N, n = e->P.n, F = e->P.F;
     const size_t abytes = N * n * (action_kind == EVC_ACTION_DISCRETE ? 8 : 4);
     if (actions_host)
-        HIP_TRY(hipMemcpyAsync(e->d_act, actions_host, abytes, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(copy_h2d(e->d_act, actions_host, abytes, e->stream));
     evc_step_out od;
     od.obs = e->d_obs; od.reward = e->d_reward; od.terminated = e->d_term;
     od.breakdown = e->d_breakdown; od.final_obs = e->d_final;
@@ -830,21 +871,21 @@ int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, 
     od.returns = nullptr;
     if (int rc = launch_step(e, e->d_act, action_kind, bins, &od)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (oh->obs) HIP_TRY(hipMemcpy(oh->obs, e->d_obs, sizeof(float) * N * F, hipMemcpyDeviceToHost));
-    if (oh->reward) HIP_TRY(hipMemcpy(oh->reward, e->d_reward, sizeof(double) * N, hipMemcpyDeviceToHost));
+    if (oh->obs) HIP_TRY(copy_d2h(oh->obs, e->d_obs, sizeof(float) * N * F, e->stream));
+    if (oh->reward) HIP_TRY(copy_d2h(oh->reward, e->d_reward, sizeof(double) * N, e->stream));
     bool any_done = true;
     if (oh->terminated) {
-        HIP_TRY(hipMemcpy(oh->terminated, e->d_term, N, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_d2h(oh->terminated, e->d_term, N, e->stream));
         any_done = false;
         for (size_t i = 0; i < N && !any_done; i++) any_done = oh->terminated[i] != 0;
     }
-    if (oh->breakdown) HIP_TRY(hipMemcpy(oh->breakdown, e->d_breakdown, sizeof(double) * N * 3, hipMemcpyDeviceToHost));
+    if (oh->breakdown) HIP_TRY(copy_d2h(oh->breakdown, e->d_breakdown, sizeof(double) * N * 3, e->stream));
     // terminal observations exist only on steps that end an episode: no N x F copy on the other 287
     if (oh->final_obs && any_done)
-        HIP_TRY(hipMemcpy(oh->final_obs, e->d_final, sizeof(float) * N * F, hipMemcpyDeviceToHost));
-    if (oh->pilots) HIP_TRY(hipMemcpy(oh->pilots, e->d_pilots, sizeof(double) * N * n, hipMemcpyDeviceToHost));
-    if (oh->rates) HIP_TRY(hipMemcpy(oh->rates, e->d_rates, sizeof(double) * N * n, hipMemcpyDeviceToHost));
-    if (oh->projected) HIP_TRY(hipMemcpy(oh->projected, e->d_proj, sizeof(double) * N * n, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_d2h(oh->final_obs, e->d_final, sizeof(float) * N * F, e->stream));
+    if (oh->pilots) HIP_TRY(copy_d2h(oh->pilots, e->d_pilots, sizeof(double) * N * n, e->stream));
+    if (oh->rates) HIP_TRY(copy_d2h(oh->rates, e->d_rates, sizeof(double) * N * n, e->stream));
+    if (oh->projected) HIP_TRY(copy_d2h(oh->projected, e->d_proj, sizeof(double) * N * n, e->stream));
     return EVC_OK;
 }
 
@@ -852,7 +893,7 @@ int evc_get_env_scalars(evc_engine* e, int32_t* out_host) {
     if (!e || !out_host) return fail(EVC_EINVAL, "null argument");
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(out_host, e->d_scal, sizeof(int4) * 2 * (size_t)e->P.N, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(out_host, e->d_scal, sizeof(int4) * 2 * (size_t)e->P.N, e->stream));
     for (int i = 0; i < e->P.N; i++) out_host[(size_t)i * 8 + 6] &= kStatusMask;   // hide the entry count
     return EVC_OK;
 }
@@ -862,13 +903,13 @@ int evc_set_env_scalars(evc_engine* e, const int32_t* in_host) {
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<int> sc((size_t)e->P.N * 8);
-    HIP_TRY(hipMemcpy(sc.data(), e->d_scal, sizeof(int4) * 2 * (size_t)e->P.N, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(sc.data(), e->d_scal, sizeof(int4) * 2 * (size_t)e->P.N, e->stream));
     for (int i = 0; i < e->P.N; i++) {               // the entry count (compact layout) belongs to the station state
         const int count_bits = sc[(size_t)i * 8 + 6] & ~kStatusMask;
         memcpy(&sc[(size_t)i * 8], &in_host[(size_t)i * 8], sizeof(int) * 8);
         sc[(size_t)i * 8 + 6] = (in_host[(size_t)i * 8 + 6] & kStatusMask) | count_bits;
     }
-    HIP_TRY(hipMemcpy(e->d_scal, sc.data(), sizeof(int4) * 2 * (size_t)e->P.N, hipMemcpyHostToDevice));
+    HIP_TRY(copy_h2d(e->d_scal, sc.data(), sizeof(int4) * 2 * (size_t)e->P.N, e->stream));
     return EVC_OK;
 }
 
@@ -878,9 +919,9 @@ int evc_get_station_state(evc_engine* e, double* rem, int16_t* dep, int16_t* est
     const size_t N = (size_t)e->P.N, n = (size_t)e->P.n, cnt = N * n;
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<int> de(cnt);
-    HIP_TRY(hipMemcpy(de.data(), e->d_depest, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(de.data(), e->d_depest, sizeof(int) * cnt, e->stream));
     if (!e->compact) {
-        if (rem) HIP_TRY(hipMemcpy(rem, e->d_rem, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+        if (rem) HIP_TRY(copy_d2h(rem, e->d_rem, sizeof(double) * cnt, e->stream));
         for (size_t i = 0; i < cnt; i++) {
             if (dep) dep[i] = (int16_t)(de[i] & 0xffff);
             if (est) est[i] = (int16_t)(de[i] >> 16);
@@ -890,8 +931,8 @@ int evc_get_station_state(evc_engine* e, double* rem, int16_t* dep, int16_t* est
     // compact layout: scatter the entries of every environment to their stations
     std::vector<double> rc(cnt);
     std::vector<int> sc(N * 8);
-    HIP_TRY(hipMemcpy(rc.data(), e->d_rem, sizeof(double) * cnt, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(sc.data(), e->d_scal, sizeof(int4) * 2 * N, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(rc.data(), e->d_rem, sizeof(double) * cnt, e->stream));
+    HIP_TRY(copy_d2h(sc.data(), e->d_scal, sizeof(int4) * 2 * N, e->stream));
     for (size_t i = 0; i < cnt; i++) {
         if (rem) rem[i] = 0.0;
         if (dep) dep[i] = (int16_t)kEmptyDep;
@@ -918,13 +959,13 @@ int evc_set_station_state(evc_engine* e, const double* rem, const int16_t* dep, 
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (!e->compact) {
         for (size_t i = 0; i < cnt; i++) de[i] = ((int)dep[i] & 0xffff) | ((int)est[i] << 16);
-        HIP_TRY(hipMemcpy(e->d_rem, rem, sizeof(double) * cnt, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(e->d_depest, de.data(), sizeof(int) * cnt, hipMemcpyHostToDevice));
+        HIP_TRY(copy_h2d(e->d_rem, rem, sizeof(double) * cnt, e->stream));
+        HIP_TRY(copy_h2d(e->d_depest, de.data(), sizeof(int) * cnt, e->stream));
         return EVC_OK;
     }
     std::vector<double> rc(cnt, 0.0);
     std::vector<int> sc(N * 8);
-    HIP_TRY(hipMemcpy(sc.data(), e->d_scal, sizeof(int4) * 2 * N, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(sc.data(), e->d_scal, sizeof(int4) * 2 * N, e->stream));
     for (size_t env = 0; env < N; env++) {
         int A = 0;
         for (size_t s = 0; s < n; s++) {
@@ -938,9 +979,9 @@ int evc_set_station_state(evc_engine* e, const double* rem, const int16_t* dep, 
         }
         sc[env * 8 + 6] = (sc[env * 8 + 6] & kStatusMask) | (A << kCountShift);
     }
-    HIP_TRY(hipMemcpy(e->d_rem, rc.data(), sizeof(double) * cnt, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_depest, de.data(), sizeof(int) * cnt, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_scal, sc.data(), sizeof(int4) * 2 * N, hipMemcpyHostToDevice));
+    HIP_TRY(copy_h2d(e->d_rem, rc.data(), sizeof(double) * cnt, e->stream));
+    HIP_TRY(copy_h2d(e->d_depest, de.data(), sizeof(int) * cnt, e->stream));
+    HIP_TRY(copy_h2d(e->d_scal, sc.data(), sizeof(int4) * 2 * N, e->stream));
     return EVC_OK;
 }
 
@@ -948,7 +989,7 @@ int evc_get_breakdown(evc_engine* e, double* out_host) {
     if (!e || !out_host) return fail(EVC_EINVAL, "null argument");
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(out_host, e->d_acc, sizeof(double) * 3 * (size_t)e->P.N, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(out_host, e->d_acc, sizeof(double) * 3 * (size_t)e->P.N, e->stream));
     return EVC_OK;
 }
 
@@ -956,7 +997,7 @@ int evc_set_breakdown(evc_engine* e, const double* in_host) {
     if (!e || !in_host) return fail(EVC_EINVAL, "null argument");
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(e->d_acc, in_host, sizeof(double) * 3 * (size_t)e->P.N, hipMemcpyHostToDevice));
+    HIP_TRY(copy_h2d(e->d_acc, in_host, sizeof(double) * 3 * (size_t)e->P.N, e->stream));
     return EVC_OK;
 }
 
@@ -977,7 +1018,7 @@ int evc_read_metrics(evc_engine* e, double* out_host) {
     hipLaunchKernelGGL(metrics_kernel, dim3(blocks), dim3(256), 0, e->stream, e->P, e->d_metrics);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(out_host, e->d_metrics, sizeof(double) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_d2h(out_host, e->d_metrics, sizeof(double) * 8, e->stream));
     out_host[3] = (double)e->env_steps;
     return EVC_OK;
 }
@@ -987,9 +1028,9 @@ int evc_last_slow_count(evc_engine* e, int32_t* count) {
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     int both[2];
-    HIP_TRY(hipMemcpy(both, e->d_slow_count, 2 * sizeof(int), hipMemcpyDeviceToHost));
-    // the counter of the most recent step has already been cleared by its slow kernel only if the
-    // NEXT step ran; the one not selected for the next step holds the last count
+    HIP_TRY(copy_d2h(both, e->d_slow_count, 2 * sizeof(int), e->stream));
+    // the control block of the most recent step is cleared by the drainer of the NEXT step; the one not
+    // selected for the next step holds the last count
     *count = both[(e->step_parity + 1) & 1];
     return EVC_OK;
 }

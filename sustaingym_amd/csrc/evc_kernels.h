@@ -392,6 +392,20 @@ __device__ __forceinline__ unsigned long long exact_rows(const Params& P, const 
     return __ballot(viol);
 }
 
+// Queue control block of one step (double-buffered by step parity): ctl[0] = number of queued environments.
+__device__ __forceinline__ int queue_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void queue_push(const Params& P, int env) {
+    const int idx = __hip_atomic_fetch_add(P.slow_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // agent-coherent store: the draining workgroup may sit on another XCD (own L2) and read it in the SAME launch
+    __hip_atomic_store(P.slow_list + idx, env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// what every drainer does first: clear the other parity's control block for the next step, report the queue
+// length to the host (page-locked ring the engine reads without synchronising, evc_engine.hip: drain mode)
+__device__ __forceinline__ void queue_begin_drain(const Params& P, int count) {
+    P.slow_count_next[0] = 0;
+    if (P.host_qlen) __hip_atomic_store(P.host_qlen, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // XCD-aware wave -> environment mapping: workgroup b runs on XCD b % 8 (observed, speed only);
 // each XCD walks one contiguous eighth of the environments so that neighbouring state rows
 // (which share cache lines) meet in the same L2.
@@ -485,7 +499,7 @@ __global__ __launch_bounds__(256) void step_kernel(Params P, StepIO io) {
                         }
                     }
                     if (!solved) {
-                        if (lane == 0) P.slow_list[atomicAdd(P.slow_count, 1)] = env;
+                        if (lane == 0) queue_push(P, env);
                         continue;                  // the solver kernel steps this environment
                     }
                 }

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
                     anyviol = anyviol && !(fill && !still);
                 }
                 const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel
-                if (queue_me && q == 0u) P.slow_list[atomicAdd(P.slow_count, 1)] = (int)env;
+                if (queue_me && q == 0u) queue_push(P, (int)env);
                 live = live && !queue_me;                 // queued rows write nothing here
                 pilots_screened = pilots_screened && !undecided;
             }

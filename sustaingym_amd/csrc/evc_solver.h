@@ -227,219 +227,226 @@ __device__ __forceinline__ void solver_small(SolverLds& L, int lane, double rhs)
     SOLVER_SYNC();
 }
 
+#ifndef EVC_SOLVE_ENV_INLINE
+#define EVC_SOLVE_ENV_INLINE __forceinline__
+#endif
+// The projection + the rest of the step for ONE queued environment, by one wavefront (lane i: station i;
+// lane c: constraint row c; lane a: row a of the Newton system).  Shared by the slow kernel and by the
+// streaming kernel's in-kernel queue drain (evc_cquad.h).
 template <int WORDS>
-__global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
-    __shared__ SolverLds L;
-    const int count = rfl(*P.slow_count);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *P.slow_count_next = 0;   // double-buffered counter
-    if ((int)blockIdx.x >= count) return;           // nothing queued for this workgroup
-    stage_net(L.net, P);
-    const int lane = threadIdx.x;
+__device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io, SolverLds& L, int lane, int env) {
     const int m = P.m, G = P.G;
     const LaneNet lnet = lane_net(P, lane);
     SolverLane ln;
     ln.gid = lnet.gid;
+    [[maybe_unused]] long long c0 = SOLVER_CLK();
+    const EnvLoads cur = issue_loads(P, io, env, lane);
+    EnvRegs r;
+    unpack_env(cur, r);
+    bool clamped;
+    const double a = unpack_action(io, cur, clamped);
+    ln.b = a * Consts::ACTION_SCALE_FACTOR;
+    ln.h = demand_cap_amps(r);
+    if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; }
+    SOLVER_SYNC();
 
-    for (int q = blockIdx.x; q < count; q += gridDim.x) {
-        [[maybe_unused]] long long c0 = SOLVER_CLK();
-        const int env = rfl(P.slow_list[q]);
-        const EnvLoads cur = issue_loads(P, io, env, lane);
-        EnvRegs r;
-        unpack_env(cur, r);
-        bool clamped;
-        const double a = unpack_action(io, cur, clamped);
-        ln.b = a * Consts::ACTION_SCALE_FACTOR;
-        ln.h = demand_cap_amps(r);
-        if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; }
-        SOLVER_SYNC();
-
-        // (a) the screen of the streaming kernel may have been merely inconclusive: exact test of
-        //     the box clip; (b) class caps (pod breakers) violated: closed-form water-filling, exact if
-        //     every row holds afterwards (relaxation argument)
-        bool settled = false;
-        {
-            const double y0 = fmin(ln.b, ln.h);
-            unsigned cap_viol;
-            const unsigned long long vrows = exact_rows(P, L.net, lnet, lane, y0, cap_viol);
-            ln.y = y0;
-            if (vrows == 0ull) {
+    // (a) the screen of the streaming kernel may have been merely inconclusive: exact test of
+    //     the box clip; (b) class caps (pod breakers) violated: closed-form water-filling, exact if
+    //     every row holds afterwards (relaxation argument)
+    bool settled = false;
+    {
+        const double y0 = fmin(ln.b, ln.h);
+        unsigned cap_viol;
+        const unsigned long long vrows = exact_rows(P, L.net, lnet, lane, y0, cap_viol);
+        ln.y = y0;
+        if (vrows == 0ull) {
+            settled = true;
+        } else if (cap_viol != 0u) {          // caps first, also beside violated multi-class rows
+            double yw = y0;
+            for (int g = 0; g < G; g++)
+                if ((cap_viol >> g) & 1u)
+                    yw = waterfill_class(lnet.gid == g, ln.b, ln.h, P.class_cap[g], yw);
+            unsigned cv2;
+            if (exact_rows(P, L.net, lnet, lane, yw, cv2) == 0ull) {
+                ln.y = yw;
                 settled = true;
-            } else if (cap_viol != 0u) {          // caps first, also beside violated multi-class rows
-                double yw = y0;
-                for (int g = 0; g < G; g++)
-                    if ((cap_viol >> g) & 1u)
-                        yw = waterfill_class(lnet.gid == g, ln.b, ln.h, P.class_cap[g], yw);
-                unsigned cv2;
-                if (exact_rows(P, L.net, lnet, lane, yw, cv2) == 0ull) {
-                    ln.y = yw;
-                    settled = true;
-                }
             }
         }
-        [[maybe_unused]] long long c1 = SOLVER_CLK();
-        SOLVER_STAT(8, c1 - c0);
-        [[maybe_unused]] long long t_build = 0, t_chol = 0, t_ls = 0, t_head = 0;
-        SOLVER_STAT(0, 1);
-        SOLVER_STAT(1, settled ? 1 : 0);
-        if (!settled) solver_pass(P, L, ln, lane, L.z);
-        [[maybe_unused]] int n_iter = 0, n_trial = 0, n_act = 0;
-
-        double mu = 1e-3;
-        bool converged = settled, last_ok = false;
-        for (int it = 0; it < kSolverMaxIter && !settled; it++) {
-            n_iter++;
-            long long ca = SOLVER_CLK();
-            double g0, g1, nz, nw;
-            row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
-            const double rc = lane < m ? L.net.mag[lane] : 1.0;
-            // activate violated rows that have no multiplier yet
-            const bool newly = lane < m && nz == 0.0 && nw > rc * (1.0 + Consts::PROJ_TOL);
-            const unsigned long long newly_rows = __ballot(newly);
-            if (newly_rows != 0ull) {
-                // First activation (no multiplier yet anywhere): start every violated row at the
-                // first-order size of its multiplier along w — moving z_c by lam w^ lowers |w_c| by
-                // about lam w^'(M_c diag(k) M_c')w^ — divided by the number of rows activated together,
-                // whose corrections add up.  (A tiny start costs several expansion passes of the line
-                // search per row: 12-15 passes per solve instead of 5; unscaled, a fully saturated
-                // network overshoots into the flat region and cycles.)  Rows that become violated
-                // later, beside active ones, start tiny and let the Newton system place them.
-                const bool first = __ballot(lane < m && nz > 0.0) == 0ull;
-                if (newly) {
-                    const double wh0 = L.w[lane][0] / nw, wh1 = L.w[lane][1] / nw;
-                    double lam = 1e-6;
-                    if (first) {
-                        double curv = 0.0;
-                        for (int g = 0; g < G; g++) {
-                            const double pr = L.net.Mre[g][lane] * wh0 + L.net.Mim[g][lane] * wh1;
-                            curv += L.kfree[g] * pr * pr;
-                        }
-                        if (curv > 0.0) lam = fmax((nw - rc) / (curv * (double)__popcll(newly_rows)), 1e-6);
-                    }
-                    L.z[lane][0] = lam * wh0;
-                    L.z[lane][1] = lam * wh1;
-                }
-                SOLVER_SYNC();
-                solver_pass(P, L, ln, lane, L.z);
-                row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
-            }
-            unsigned long long active = __ballot(lane < m && nz > 0.0);
-            // convergence test
-            double res = 0.0;
-            bool inact = true;
-            if (lane < m) {
-                inact = !(nz > 0.0);
-                res = inact ? (nw / rc - 1.0) : sqrt(g0 * g0 + g1 * g1) / rc;
-            }
-            const unsigned long long bad_inact = __ballot(inact && res > Consts::PROJ_TOL);
-            if (bad_inact == 0ull && __ballot(!inact && res > Consts::PROJ_TOL_KKT) == 0ull) {
-                converged = true;
-                break;
-            }
-            last_ok = bad_inact == 0ull && __ballot(!inact && res > Consts::PROJ_TOL_ACCEPT) == 0ull;
-            // keep the Newton system within kMaxActive rows (drop the least violated extras)
-            while (__popcll(active) > kMaxActive) {
-                const int last = 63 - __clzll(active);
-                active &= ~(1ull << last);
-            }
-            const int na = __popcll(active);
-            n_act = na;
-            long long cb = SOLVER_CLK(); t_head += cb - ca;
-            const int d = 2 * na;
-            const bool mine = lane < m && ((active >> lane) & 1ull);
-            const int jrow = __popcll(active & ((1ull << lane) - 1ull));
-            if (mine) L.act[jrow] = lane;
-            SOLVER_SYNC();
-            // Newton system, one ELEMENT per lane (d*d <= 1024 elements, row a = 2*j + p <-> active row
-            // act[j], component p): H_ab = sum_g M_a[g] k_g M_b[g]  (+ the curvature of r_c ||z_c|| on the
-            // 2x2 diagonal blocks); rhs = gradient of the active rows.
-            if (mine) {
-                const double z0 = L.z[lane][0], z1 = L.z[lane][1];
-                const double nzc = sqrt(z0 * z0 + z1 * z1);
-                L.zn[lane] = nzc; L.zh[lane][0] = z0 / nzc; L.zh[lane][1] = z1 / nzc;
-            }
-            SOLVER_SYNC();
-            for (int e = lane; e < d * d; e += kWave) {
-                const int a = e / d, bcol = e - a * d;
-                const int ja = a >> 1, pa = a & 1, ca = L.act[ja];
-                const int jb = bcol >> 1, pb = bcol & 1, cb = L.act[jb];
-                double hsum = 0.0;
-                for (int g = 0; g < G; g++) {
-                    const double ma = pa ? L.net.Mim[g][ca] : L.net.Mre[g][ca];
-                    const double mb = pb ? L.net.Mim[g][cb] : L.net.Mre[g][cb];
-                    hsum += ma * L.kfree[g] * mb;
-                }
-                if (jb == ja)
-                    hsum += (L.net.mag[ca] / L.zn[ca]) * ((pa == pb ? 1.0 : 0.0) - L.zh[ca][pa] * L.zh[ca][pb]);
-                L.H[a][bcol] = hsum;
-            }
-            double rhs = 0.0;
-            if (lane < d) {
-                const int ca = L.act[lane >> 1], pa = lane & 1;
-                rhs = L.w[ca][pa] - L.net.mag[ca] * L.zh[ca][pa];
-            }
-            SOLVER_SYNC();
-            double tr = wave_sum_f64(lane < d ? L.H[lane][lane] : 0.0);
-            double scale = tr / (double)d;
-            scale = scale < 1e-12 ? 1e-12 : scale;
-            if (lane < d) L.H[lane][lane] += mu * scale;
-            SOLVER_SYNC();
-            const double grad_a = rhs;
-            long long cc = SOLVER_CLK(); t_build += cc - cb;
-            if (d == 2) solver_small<2>(L, lane, rhs);          // one active row: the usual case
-            else if (d == 4) solver_small<4>(L, lane, rhs);
-            else solver_cholesky(L, d, lane, rhs);
-            const double dd0 = wave_sum_f64(lane < d ? grad_a * L.dir[lane] : 0.0);
-
-            long long cd = SOLVER_CLK(); t_chol += cd - cc;
-            // line search on the sign of the directional derivative
-            double alpha = 1.0;
-            double dd = solver_trial(P, L, ln, lane, active, alpha);
-            n_trial++;
-            bool state_current = true;            // L.w / L.S / L.kfree / ln.y belong to the accepted point
-            if (dd > 0.25 * dd0) {
-                // undershoot (flat piece): expand while the derivative stays positive
-                accept_trial(L, m, lane);         // alpha = 1 is an ascent point
-                double best_alpha = 1.0;
-                // z was overwritten: trials are taken relative to the ORIGINAL point, so keep
-                // the displacement bookkeeping simple by expanding from the accepted point.
-                while (dd > 0.25 * dd0 && best_alpha < 1e6) {
-                    const double dd2 = solver_trial(P, L, ln, lane, active, 3.0 * best_alpha);
-                    n_trial++;
-                    if (dd2 < -0.5 * dd0) { state_current = false; break; }     // rejected trial
-                    accept_trial(L, m, lane);
-                    best_alpha *= 4.0;
-                    dd = dd2;
-                }
-                mu = fmax(mu * 0.1, 1e-12);
-            } else {
-                int nback = 0;
-                while (dd < -0.5 * dd0 && alpha > 1e-8) {
-                    alpha *= 0.5;
-                    nback++;
-                    dd = solver_trial(P, L, ln, lane, active, alpha);
-                    n_trial++;
-                }
-                accept_trial(L, m, lane);
-                mu = (nback > 1) ? mu * 4.0 : fmax(mu * 0.25, 1e-12);
-            }
-            // the pass of the last trial already left the state of the accepted point, unless that
-            // trial was rejected
-            if (!state_current) solver_pass(P, L, ln, lane, L.z);
-            t_ls += SOLVER_CLK() - cd;
-        }
-        [[maybe_unused]] long long c2 = SOLVER_CLK();
-        SOLVER_STAT(9, c2 - c1); SOLVER_STAT(10, t_head); SOLVER_STAT(11, t_build); SOLVER_STAT(12, t_chol); SOLVER_STAT(13, t_ls);
-        SOLVER_STAT(2, n_iter); SOLVER_STAT(3, n_trial); SOLVER_STAT(4, n_act); SOLVER_STAT(5, n_iter >= 20 ? 1 : 0);
-        SOLVER_STAT(6, n_act == 1 ? 1 : 0); SOLVER_STAT(7, (!converged && !last_ok) ? 1 : 0);
-        if (!converged && !last_ok) r.status |= EVC_STATUS_PROJ_NOCONV;
-        // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
-        // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
-        double y = ln.y;
-        if (y != fmin(ln.b, ln.h)) y = tie_snap(y, ln.h);
-        finish_step<WORDS>(P, io, L.net, lnet, env, lane, y, clamped, cur.acc, false, r);
-        SOLVER_STAT(14, SOLVER_CLK() - c2);
-        SOLVER_SYNC();
     }
+    [[maybe_unused]] long long c1 = SOLVER_CLK();
+    SOLVER_STAT(8, c1 - c0);
+    [[maybe_unused]] long long t_build = 0, t_chol = 0, t_ls = 0, t_head = 0;
+    SOLVER_STAT(0, 1);
+    SOLVER_STAT(1, settled ? 1 : 0);
+    if (!settled) solver_pass(P, L, ln, lane, L.z);
+    [[maybe_unused]] int n_iter = 0, n_trial = 0, n_act = 0;
+
+    double mu = 1e-3;
+    bool converged = settled, last_ok = false;
+    for (int it = 0; it < kSolverMaxIter && !settled; it++) {
+        n_iter++;
+        long long ca = SOLVER_CLK();
+        double g0, g1, nz, nw;
+        row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
+        const double rc = lane < m ? L.net.mag[lane] : 1.0;
+        // activate violated rows that have no multiplier yet
+        const bool newly = lane < m && nz == 0.0 && nw > rc * (1.0 + Consts::PROJ_TOL);
+        const unsigned long long newly_rows = __ballot(newly);
+        if (newly_rows != 0ull) {
+            // First activation (no multiplier yet anywhere): start every violated row at the
+            // first-order size of its multiplier along w — moving z_c by lam w^ lowers |w_c| by
+            // about lam w^'(M_c diag(k) M_c')w^ — divided by the number of rows activated together,
+            // whose corrections add up.  (A tiny start costs several expansion passes of the line
+            // search per row: 12-15 passes per solve instead of 5; unscaled, a fully saturated
+            // network overshoots into the flat region and cycles.)  Rows that become violated
+            // later, beside active ones, start tiny and let the Newton system place them.
+            const bool first = __ballot(lane < m && nz > 0.0) == 0ull;
+            if (newly) {
+                const double wh0 = L.w[lane][0] / nw, wh1 = L.w[lane][1] / nw;
+                double lam = 1e-6;
+                if (first) {
+                    double curv = 0.0;
+                    for (int g = 0; g < G; g++) {
+                        const double pr = L.net.Mre[g][lane] * wh0 + L.net.Mim[g][lane] * wh1;
+                        curv += L.kfree[g] * pr * pr;
+                    }
+                    if (curv > 0.0) lam = fmax((nw - rc) / (curv * (double)__popcll(newly_rows)), 1e-6);
+                }
+                L.z[lane][0] = lam * wh0;
+                L.z[lane][1] = lam * wh1;
+            }
+            SOLVER_SYNC();
+            solver_pass(P, L, ln, lane, L.z);
+            row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
+        }
+        unsigned long long active = __ballot(lane < m && nz > 0.0);
+        // convergence test
+        double res = 0.0;
+        bool inact = true;
+        if (lane < m) {
+            inact = !(nz > 0.0);
+            res = inact ? (nw / rc - 1.0) : sqrt(g0 * g0 + g1 * g1) / rc;
+        }
+        const unsigned long long bad_inact = __ballot(inact && res > Consts::PROJ_TOL);
+        if (bad_inact == 0ull && __ballot(!inact && res > Consts::PROJ_TOL_KKT) == 0ull) {
+            converged = true;
+            break;
+        }
+        last_ok = bad_inact == 0ull && __ballot(!inact && res > Consts::PROJ_TOL_ACCEPT) == 0ull;
+        // keep the Newton system within kMaxActive rows (drop the least violated extras)
+        while (__popcll(active) > kMaxActive) {
+            const int last = 63 - __clzll(active);
+            active &= ~(1ull << last);
+        }
+        const int na = __popcll(active);
+        n_act = na;
+        long long cb = SOLVER_CLK(); t_head += cb - ca;
+        const int d = 2 * na;
+        const bool mine = lane < m && ((active >> lane) & 1ull);
+        const int jrow = __popcll(active & ((1ull << lane) - 1ull));
+        if (mine) L.act[jrow] = lane;
+        SOLVER_SYNC();
+        // Newton system, one ELEMENT per lane (d*d <= 1024 elements, row a = 2*j + p <-> active row
+        // act[j], component p): H_ab = sum_g M_a[g] k_g M_b[g]  (+ the curvature of r_c ||z_c|| on the
+        // 2x2 diagonal blocks); rhs = gradient of the active rows.
+        if (mine) {
+            const double z0 = L.z[lane][0], z1 = L.z[lane][1];
+            const double nzc = sqrt(z0 * z0 + z1 * z1);
+            L.zn[lane] = nzc; L.zh[lane][0] = z0 / nzc; L.zh[lane][1] = z1 / nzc;
+        }
+        SOLVER_SYNC();
+        for (int e = lane; e < d * d; e += kWave) {
+            const int a = e / d, bcol = e - a * d;
+            const int ja = a >> 1, pa = a & 1, ca = L.act[ja];
+            const int jb = bcol >> 1, pb = bcol & 1, cb = L.act[jb];
+            double hsum = 0.0;
+            for (int g = 0; g < G; g++) {
+                const double ma = pa ? L.net.Mim[g][ca] : L.net.Mre[g][ca];
+                const double mb = pb ? L.net.Mim[g][cb] : L.net.Mre[g][cb];
+                hsum += ma * L.kfree[g] * mb;
+            }
+            if (jb == ja)
+                hsum += (L.net.mag[ca] / L.zn[ca]) * ((pa == pb ? 1.0 : 0.0) - L.zh[ca][pa] * L.zh[ca][pb]);
+            L.H[a][bcol] = hsum;
+        }
+        double rhs = 0.0;
+        if (lane < d) {
+            const int ca = L.act[lane >> 1], pa = lane & 1;
+            rhs = L.w[ca][pa] - L.net.mag[ca] * L.zh[ca][pa];
+        }
+        SOLVER_SYNC();
+        double tr = wave_sum_f64(lane < d ? L.H[lane][lane] : 0.0);
+        double scale = tr / (double)d;
+        scale = scale < 1e-12 ? 1e-12 : scale;
+        if (lane < d) L.H[lane][lane] += mu * scale;
+        SOLVER_SYNC();
+        const double grad_a = rhs;
+        long long cc = SOLVER_CLK(); t_build += cc - cb;
+        if (d == 2) solver_small<2>(L, lane, rhs);          // one active row: the usual case
+        else if (d == 4) solver_small<4>(L, lane, rhs);
+        else solver_cholesky(L, d, lane, rhs);
+        const double dd0 = wave_sum_f64(lane < d ? grad_a * L.dir[lane] : 0.0);
+
+        long long cd = SOLVER_CLK(); t_chol += cd - cc;
+        // line search on the sign of the directional derivative
+        double alpha = 1.0;
+        double dd = solver_trial(P, L, ln, lane, active, alpha);
+        n_trial++;
+        bool state_current = true;            // L.w / L.S / L.kfree / ln.y belong to the accepted point
+        if (dd > 0.25 * dd0) {
+            // undershoot (flat piece): expand while the derivative stays positive
+            accept_trial(L, m, lane);         // alpha = 1 is an ascent point
+            double best_alpha = 1.0;
+            // z was overwritten: trials are taken relative to the ORIGINAL point, so keep
+            // the displacement bookkeeping simple by expanding from the accepted point.
+            while (dd > 0.25 * dd0 && best_alpha < 1e6) {
+                const double dd2 = solver_trial(P, L, ln, lane, active, 3.0 * best_alpha);
+                n_trial++;
+                if (dd2 < -0.5 * dd0) { state_current = false; break; }     // rejected trial
+                accept_trial(L, m, lane);
+                best_alpha *= 4.0;
+                dd = dd2;
+            }
+            mu = fmax(mu * 0.1, 1e-12);
+        } else {
+            int nback = 0;
+            while (dd < -0.5 * dd0 && alpha > 1e-8) {
+                alpha *= 0.5;
+                nback++;
+                dd = solver_trial(P, L, ln, lane, active, alpha);
+                n_trial++;
+            }
+            accept_trial(L, m, lane);
+            mu = (nback > 1) ? mu * 4.0 : fmax(mu * 0.25, 1e-12);
+        }
+        // the pass of the last trial already left the state of the accepted point, unless that
+        // trial was rejected
+        if (!state_current) solver_pass(P, L, ln, lane, L.z);
+        t_ls += SOLVER_CLK() - cd;
+    }
+    [[maybe_unused]] long long c2 = SOLVER_CLK();
+    SOLVER_STAT(9, c2 - c1); SOLVER_STAT(10, t_head); SOLVER_STAT(11, t_build); SOLVER_STAT(12, t_chol); SOLVER_STAT(13, t_ls);
+    SOLVER_STAT(2, n_iter); SOLVER_STAT(3, n_trial); SOLVER_STAT(4, n_act); SOLVER_STAT(5, n_iter >= 20 ? 1 : 0);
+    SOLVER_STAT(6, n_act == 1 ? 1 : 0); SOLVER_STAT(7, (!converged && !last_ok) ? 1 : 0);
+    if (!converged && !last_ok) r.status |= EVC_STATUS_PROJ_NOCONV;
+    // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
+    // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
+    double y = ln.y;
+    if (y != fmin(ln.b, ln.h)) y = tie_snap(y, ln.h);
+    finish_step<WORDS>(P, io, L.net, lnet, env, lane, y, clamped, cur.acc, false, r);
+    SOLVER_STAT(14, SOLVER_CLK() - c2);
+    SOLVER_SYNC();
+}
+
+template <int WORDS>
+__global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
+    __shared__ SolverLds L;
+    const int count = rfl(*P.slow_count);
+    if (blockIdx.x == 0 && threadIdx.x == 0) queue_begin_drain(P, count);
+    if ((int)blockIdx.x >= count) return;           // nothing queued for this workgroup
+    stage_net(L.net, P);
+    const int lane = threadIdx.x;
+    for (int q = blockIdx.x; q < count; q += gridDim.x) solve_env<WORDS>(P, io, L, lane, rfl(P.slow_list[q]));
 }
 
 }  // namespace evc

@@ -154,3 +154,44 @@ def test_device_generator_reproduces_the_golden_episodes():
         assert np.array_equal(req.view(np.uint64), gold[f'req_{i}'].view(np.uint64))
         assert np.allclose(mp, gold[f'mp_{i}'], rtol=1e-13, atol=1e-12)
         eng.close()
+
+
+def test_download_stress_under_host_load():
+    """Regression / stress for the intermittent 'Memory access fault by GPU' of rounds 1-2: it
+    appeared at the first synchronisation of evc_download_episodes — back-to-back device-to-host copies into
+    adjacent pageable numpy arrays — in 2-3 of ~60 suite runs, only after oracle-heavy tests (idle OpenMP workers
+    still spinning on every granted CPU).  Since the library stages every transfer through its own page-locked
+    buffers (csrc/evc_hostcopy.h) the runtime never pins caller memory.  20 rounds of create / generate /
+    download / upload / state round trip with the OpenMP pool kept hot in between; contents checked each time."""
+    from oracle import binding as ob
+    from helpers import make_workload
+    net = site_str_to_site('caltech')
+    tabs = gmm_device_tables('caltech', 'Summer 2019')
+    wl = make_workload(net, 256, seed=5)
+    bat = ob.OracleBatch(ob.OracleNetwork(net), 256, 36, False)
+    bat.set_bank(wl['n_sessions'], wl['sessions'], wl['requested'], wl['moer_day'], wl['moer'])
+    bat.reset()
+    rng = np.random.default_rng(0)
+    ref = None
+    for it in range(20):
+        for _ in range(3):                                   # keeps every OpenMP worker spinning
+            bat.step(rng.random((256, net.num_stations), dtype=np.float32), debug=False)
+        count = 2500 + 300 * (it % 5)
+        from sustaingym_amd.engine import StepEngine
+        eng = StepEngine(net, 64, bank_slots=count + 10, max_sessions=128, moer_days=tabs['num_days'])
+        eng.upload_gmm(tabs)
+        eng.generate_episodes(5, count, 99, 1000)
+        ns, sess, req, day, mp = eng.download_episodes(5, count)
+        if ref is None:
+            ref = (ns[:2500].copy(), sess[:2500].copy(), req[:2500].copy(), day[:2500].copy())
+        for got, want in zip((ns, sess, req, day), ref):     # same (seed, episode) -> same bank, every round
+            assert np.array_equal(got[:2500].view(np.uint8), want.view(np.uint8)), it
+        eng.upload_episodes(ns, sess, req, day, first_slot=3)         # and back up, shifted by two slots
+        again = eng.download_episodes(3, count)
+        assert np.array_equal(again[1].view(np.int16), sess.view(np.int16))
+        assert np.array_equal(again[2].view(np.uint64), req.view(np.uint64))
+        st = eng.get_state()
+        eng.set_state(st)
+        for key, val in eng.get_state().items():
+            assert np.array_equal(val, st[key]), key
+        eng.close()
