@@ -480,6 +480,7 @@ struct orc_batch {
     const orc_net* net;
     int N, k, project;
     orc_env** envs;
+    orc_env* block;
     int32_t* slot;
     /* bank (borrowed copies) */
     int bank_slots, stride, moer_days;
@@ -498,7 +499,20 @@ orc_batch* orc_batch_create(const orc_net* net, int N, int k, int project) {
     b->project = project;
     b->envs = (orc_env**)calloc((size_t)N, sizeof(orc_env*));
     b->slot = (int32_t*)calloc((size_t)N, sizeof(int32_t));
-    for (int i = 0; i < N; i++) b->envs[i] = orc_env_create(net, k, project);
+    /* ONE block for all environments (an orc_env is ~112 kB: as 65 536 separate callocs a full-size batch grew
+     * the brk heap to 7.8 GB and shrank it again at destroy; the GPU test-suite's intermittent "Memory access
+     * fault by GPU" hit exactly such addresses shortly afterwards).  A block this size is
+     * mmap'ed and unmapped as a whole. */
+    b->block = (orc_env*)calloc((size_t)N, sizeof(orc_env));
+    for (int i = 0; i < N; i++) {
+        orc_env* e = &b->block[i];
+        e->net = net;
+        e->k = k;
+        e->project = project;
+        e->done = 1;
+        for (int j = 0; j < ORC_MAX_STATIONS; j++) e->evse_ev[j] = -1;
+        b->envs[i] = e;
+    }
     return b;
 }
 
@@ -517,7 +531,7 @@ static void batch_free_bank(orc_batch* b) {
 
 void orc_batch_destroy(orc_batch* b) {
     if (!b) return;
-    for (int i = 0; i < b->N; i++) orc_env_destroy(b->envs[i]);
+    free(b->block);
     free(b->envs);
     free(b->slot);
     batch_free_bank(b);

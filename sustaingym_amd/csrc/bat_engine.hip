@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "evc_hostcopy.h"
+using evc::copy_d2h;
+using evc::copy_h2d;
 
 #include "../../include/battery_dispatch.h"
 
