@@ -237,6 +237,7 @@ def roofline_record(w: EvWorkload, timed: dict, bytes_per_env_step: int) -> dict
 def cpu_baseline_record(args, w: EvWorkload) -> dict:
     """The oracle (scalar C restatement, oracle/) on the host cores: bounded sample of the same workload."""
     from oracle import binding as ob
+    from sustaingym_amd.hostio import to_host
     cn, cs = min(args.cpu_envs, w.N), args.cpu_steps
     ns, sess, req, day = w.bank
     bat = ob.OracleBatch(ob.OracleNetwork(w.net), cn, w.k, w.project, args.battery)
@@ -250,7 +251,7 @@ def cpu_baseline_record(args, w: EvWorkload) -> dict:
     host = {'cpu_count': os.cpu_count(), 'affinity': len(os.sched_getaffinity(0)), 'cgroup_cpus': cgroup_cpus,
             'omp_max_threads': ob.max_threads()}
     cores = ob.default_threads()        # one thread per CPU this process may really use (cgroup quota)
-    acts = [r[:cn].cpu().numpy() for r in w.ring]
+    acts = [to_host(r[:cn]) for r in w.ring]
     # skip the empty early-morning periods so that the sample has plugged-in EVs; their rate sizes the timed
     # sample to ~3 s of wall time on whatever host this is (bounded: --cpu-steps .. 2304 steps = 8 days)
     t1 = time.perf_counter()

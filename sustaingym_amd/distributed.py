@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .hostio import to_host
+
 METRIC_NAMES = ('profit', 'carbon_cost', 'excess_charge', 'env_steps', 'episodes_finished',
                 'envs_with_status')
 
@@ -66,7 +68,7 @@ def all_gather_vector(local: np.ndarray, device=None) -> np.ndarray:
     t = torch.as_tensor(local, dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
-    return torch.stack(out).cpu().numpy()
+    return to_host(torch.stack(out))
 
 
 def metrics_vector(metrics: dict[str, float]) -> np.ndarray:
@@ -84,7 +86,7 @@ def all_gather_metrics(local: np.ndarray, device=None):
     t = torch.as_tensor(local, dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
-    per_rank = torch.stack(out).cpu().numpy()
+    per_rank = to_host(torch.stack(out))
     return per_rank, per_rank.sum(axis=0)
 
 

@@ -19,6 +19,7 @@ from typing import Iterable, Sequence
 import numpy as np
 
 from . import _lib
+from .hostio import to_host
 from .engine import StepEngine
 from .event_generation import AbstractTraceGenerator
 from .network import site_str_to_site
@@ -102,8 +103,8 @@ class PolicyRollout:
             out = eng.rollout(policy=self.policy, steps=EPISODE_STEPS, bins=self.bins)
             torch.cuda.synchronize(self.device)
             assert bool(out['terminated'].all()), 'episodes must end after 288 periods'
-            returns = out['returns'].cpu().numpy().copy()
-            breakdown = out['breakdown'].cpu().numpy().copy()
+            returns = to_host(out['returns']).copy()
+            breakdown = to_host(out['breakdown']).copy()
             status = eng.env_scalars()['status']
         finally:
             eng.close()

@@ -3,6 +3,7 @@
 determinism on seed, 288-step episodes, agents == [] after termination) plus parity of the
 single-env API against the oracle on REAL trace days."""
 import numpy as np
+from sustaingym_amd.hostio import to_device, to_host
 import pytest
 
 from oracle import binding as ob
@@ -252,7 +253,7 @@ def test_random_policy_bit_exact_and_rollout(bins):
     for t in range(288 + 20):                          # crosses an autoreset boundary
         episode, tt = divmod(t, 288)
         want = ob.random_actions(2024, ids, episode, tt, n, bins)
-        got = eng.fill_random_actions(bins=bins).cpu().numpy()
+        got = to_host(eng.fill_random_actions(bins=bins))
         assert np.array_equal(got, want), f't={t}'
         assert got.min() >= 0.0 and got.max() <= (1.0 if bins else np.float32(1.0 - 2.0 ** -24))
         g = eng.step_policy('random', bins=bins)
@@ -278,7 +279,7 @@ def test_random_policy_bit_exact_and_rollout(bins):
     ret = np.zeros(N)
     for tt in range(288):
         ret += bat.step(ob.random_actions(2024, ids, 0, tt, n, bins), debug=False)['reward']
-    np.testing.assert_allclose(out['returns'].cpu().numpy(), ret, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(to_host(out['returns']), ret, rtol=1e-9, atol=1e-12)
     eng.close()
 
 
@@ -298,12 +299,12 @@ def test_multiagent_vector_env_matches_single_multiagent_env(delay):
     s_obs = [e.reset(seed=50 + i)[0] for i, e in enumerate(singles)]
     assert obs.shape == (N, n, 146)
     for i in range(N):
-        assert np.array_equal(obs[i, 0].cpu().numpy(), s_obs[i][singles[i].possible_agents[0]])
+        assert np.array_equal(to_host(obs[i, 0]), s_obs[i][singles[i].possible_agents[0]])
     rng = np.random.default_rng(1)
     for t in range(150):
         a = rng.random((N, n), dtype=np.float32)
-        obs, rew, term, trunc, info = venv.step(torch.from_numpy(a).cuda())
-        got = obs.cpu().numpy()
+        obs, rew, term, trunc, info = venv.step(to_device(a))
+        got = to_host(obs)
         for i, e in enumerate(singles):
             so, sr, st, _, _ = e.step({ag: a[i, j:j + 1] for j, ag in enumerate(e.possible_agents)})
             for j in (0, 17, 53):
@@ -326,15 +327,15 @@ def test_vector_env_torch_output_stays_on_device():
     rng = np.random.default_rng(2)
     for t in range(288):
         a = rng.random((N, 52), dtype=np.float32)
-        obs, rew, term, trunc, info = venv.step(torch.from_numpy(a).cuda())
+        obs, rew, term, trunc, info = venv.step(to_device(a))
         hobs, hrew, hterm, _, hinfo = host.step(a)
         assert rew.is_cuda and term.dtype == torch.bool
-        assert np.array_equal(rew.cpu().numpy(), hrew) and np.array_equal(term.cpu().numpy(), hterm)
+        assert np.array_equal(to_host(rew), hrew) and np.array_equal(to_host(term), hterm)
         # after the autoreset at step 288 the two vector envs play different (unseeded) episodes,
         # like two reference envs would after reset(seed=None); compare the terminal observation
         src, hsrc = (obs, hobs) if t < 287 else (info['final_observation'], hinfo['final_observation'])
         for key in hobs:
-            assert np.array_equal(src[key].cpu().numpy(), hsrc[key]), (key, t)
+            assert np.array_equal(to_host(src[key]), hsrc[key]), (key, t)
     assert bool(term.all())
     venv.close()
     host.close()

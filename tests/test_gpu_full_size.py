@@ -7,6 +7,7 @@ battery, the 288-step episode length, and agreement of the two kernel families
 (4-environments-per-wavefront vs 1-environment-per-wavefront), and (iii) bench.py's own workload
 replayed in full by the oracle for a day and the episode boundary, every output compared."""
 import numpy as np
+from sustaingym_amd.hostio import to_device, to_host
 import pytest
 
 from helpers import make_workload
@@ -45,7 +46,7 @@ def test_full_size_sampled_parity_and_invariants(site, monkeypatch):
     bat = ob.OracleBatch(onet, len(sample), 36, True)
     bat.set_bank(wl['n_sessions'], wl['sessions'], wl['requested'], wl['moer_day'], wl['moer'])
     bat.reset((sample % P).astype(np.int32))
-    sidx = torch.from_numpy(sample).cuda()
+    sidx = to_device(sample)
 
     gen = torch.Generator(device='cuda')
     gen.manual_seed(99)
@@ -64,12 +65,12 @@ def test_full_size_sampled_parity_and_invariants(site, monkeypatch):
             assert torch.allclose(out['obs'][:, :n], out_w['obs'][:, :n], rtol=2e-7, atol=0), t
             assert torch.allclose(out['reward'], out_w['reward'], rtol=1e-11, atol=1e-15), t
             assert torch.allclose(out['breakdown'], out_w['breakdown'], rtol=1e-11, atol=1e-13), t
-        o = bat.step(a[sidx].cpu().numpy())
-        g_obs = out['obs'][sidx].cpu().numpy()
+        o = bat.step(to_host(a[sidx]))
+        g_obs = to_host(out['obs'][sidx])
         assert np.array_equal(g_obs[:, n:], o['obs'][:, n:]), t
         np.testing.assert_allclose(g_obs[:, :n], o['obs'][:, :n], rtol=2e-7, atol=0)
-        np.testing.assert_allclose(out['reward'][sidx].cpu().numpy(), o['reward'], rtol=1e-9, atol=1e-13)
-        assert np.array_equal(out['terminated'][sidx].cpu().numpy(), o['terminated'])
+        np.testing.assert_allclose(to_host(out['reward'][sidx]), o['reward'], rtol=1e-9, atol=1e-13)
+        assert np.array_equal(to_host(out['terminated'][sidx]), o['terminated'])
     # ---- invariants over the whole batch ----
     assert bool(out['terminated'].all())                                  # every episode ends at step 288
     bd = out['breakdown']
@@ -79,7 +80,7 @@ def test_full_size_sampled_parity_and_invariants(site, monkeypatch):
     bits = {b: int(np.sum((sc['status'] & b) != 0)) for b in (1, 2, 4)}
     assert not any(bits.values()), f'status bits set (1=occupied, 2=projection not converged, 4=step after done): {bits}'
     # energy conservation: profit = PROFIT_FACTOR * sum(rates) and delivered energy <= requested
-    delivered_kwh = bd[:, 0].cpu().numpy() / (0.15 * 0.20)
+    delivered_kwh = to_host(bd[:, 0]) / (0.15 * 0.20)
     slots = np.arange(N) % P
     requested = np.array([wl['requested'][s, :wl['n_sessions'][s]].sum() for s in range(P)])[slots]
     assert np.all(delivered_kwh <= requested + 1e-6)
@@ -114,9 +115,9 @@ def test_bench_workload_every_output_against_the_oracle(site):
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
     ring = [torch.rand((N, n), device='cuda', generator=gen) for _ in range(4)]
-    ring_h = [r.cpu().numpy() for r in ring]
+    ring_h = [to_host(r) for r in ring]
     for t in range(300):
-        g = {k: v.cpu().numpy() for k, v in eng.step(ring[t % 4]).items()}
+        g = {k: to_host(v) for k, v in eng.step(ring[t % 4]).items()}
         o = orc.step(ring_h[t % 4], autoreset=True, debug=False)
         assert np.array_equal(g['terminated'], o['terminated']), t
         assert np.array_equal(g['obs'][:, n:], o['obs'][:, n:]), t              # est_departures, MOER, timestep
@@ -188,28 +189,28 @@ def test_config5_multiagent_8192x54_against_oracle_observations(delay):
     orc = ob.OracleBatch(ob.OracleNetwork(venv.venv.cn), N, 36, True)
     orc.set_bank(ns, sess, req, day, moer, autoreset_stride=N)
     o_hist = [orc.reset(np.arange(N, dtype=np.int32))]
-    g_hist = [eng.device_outputs()['obs'].cpu().numpy().copy()]
+    g_hist = [to_host(eng.device_outputs()['obs']).copy()]
     assert np.array_equal(g_hist[0], o_hist[0])
     assert tuple(obs.shape) == (N, n, F)
-    assert np.array_equal(obs.cpu().numpy(), _expected_agent_obs(g_hist[0], None, n))
+    assert np.array_equal(to_host(obs), _expected_agent_obs(g_hist[0], None, n))
     tgen = torch.Generator(device='cuda')
     tgen.manual_seed(3)
     check_at = set(range(1, 7)) | set(range(284, 296)) | set(range(40, 280, 47))
     for t in range(1, 296):
         a = torch.rand((N, n), device='cuda', generator=tgen)
         obs, rew, term, trunc, info = venv.step(a)
-        o = orc.step(a.cpu().numpy(), autoreset=True, debug=False)
+        o = orc.step(to_host(a), autoreset=True, debug=False)
         if t == 288:                                        # autoreset: the histories restart
             assert o['terminated'].all() and bool(term.all())
             o_hist, g_hist = [], []
         o_hist.append(o['obs'])
-        g_hist.append(eng.device_outputs()['obs'].cpu().numpy().copy())
-        np.testing.assert_allclose(rew[:, 0].cpu().numpy(), o['reward'] / n, rtol=1e-9, atol=1e-14)
+        g_hist.append(to_host(eng.device_outputs()['obs']).copy())
+        np.testing.assert_allclose(to_host(rew[:, 0]), o['reward'] / n, rtol=1e-9, atol=1e-14)
         if t not in check_at:
             continue
         j = len(o_hist) - 1                                 # steps since the last (auto)reset
         dl = None if (delay == 0 or j == 0) else max(0, j - delay)
-        got = obs.cpu().numpy()
+        got = to_host(obs)
         want_g = _expected_agent_obs(g_hist[j], None if dl is None else g_hist[dl], n)
         assert np.array_equal(got, want_g), f'step {t}: gather kernel / ring vs numpy on the engine observations'
         want_o = _expected_agent_obs(o_hist[j], None if dl is None else o_hist[dl], n)

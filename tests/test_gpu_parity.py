@@ -2,6 +2,7 @@
 same seeded inputs.  Bar: bit-exact integers (pilots, est_departures, event state, done flags),
 floats within 1e-9 relative (north_star asks for 1e-5)."""
 import numpy as np
+from sustaingym_amd.hostio import to_device, to_host
 import pytest
 
 from helpers import assert_step_parity, make_pair, make_workload
@@ -228,14 +229,14 @@ def test_device_tensor_path_matches_host_path(caltech):
     eng_h, _ = make_pair(caltech, N, wl, project=True)
     obs_d = eng_d.reset()
     obs_h = eng_h.reset(host=True)
-    assert np.array_equal(obs_d.cpu().numpy(), obs_h)
+    assert np.array_equal(to_host(obs_d), obs_h)
     rng = np.random.default_rng(5)
     for t in range(60):
         a = rng.random((N, n), dtype=np.float32)
-        out_d = eng_d.step(torch.from_numpy(a).cuda())
+        out_d = eng_d.step(to_device(a))
         out_h = eng_h.step(a)
         for key in ('obs', 'reward', 'terminated', 'breakdown', 'pilots', 'rates'):
-            assert np.array_equal(out_d[key].cpu().numpy(), out_h[key]), (key, t)
+            assert np.array_equal(to_host(out_d[key]), out_h[key]), (key, t)
     m = eng_d.read_metrics()
     assert m['env_steps'] == 60 * N
     assert abs(m['profit'] - out_h['breakdown'][:, 0].sum()) < 1e-9
