@@ -578,9 +578,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
                 const int next = (slot + P.autoreset_stride) % P.bank_slots;
                 slot = next;
                 t = 0; cursor = 0;
+                // three independent loads, issued together (one round trip; a load behind `n_sessions > 0` made it two,
+                // and with staggered episode phases some wavefront pays this tail in every launch)
+                const int first_arrival = (int)P.sessions[(size_t)next * P.max_sessions].arrival;
                 moer_day = P.slot_moer_day[next];
                 n_sessions = P.n_sessions[next];
-                next_arrival = n_sessions > 0 ? (int)P.sessions[(size_t)next * P.max_sessions].arrival : kNoArrival;
+                next_arrival = n_sessions > 0 ? first_arrival : kNoArrival;
                 count = 0u;
 #pragma unroll
                 for (int j = 0; j < kSlots; j++) d[j] = make_float2(0.0f, 0.0f);

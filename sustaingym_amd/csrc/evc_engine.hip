@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <climits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -51,10 +52,8 @@ hipError_t dmalloc(T** p, size_t count) {
 }  // namespace
 
 constexpr bool kDefaultCompact = true;
-constexpr int kQlenRing = 64;
-constexpr int kDrainMaxQueue = 32;      // in-kernel drain while the recent per-step totals stay at or below this ...
-constexpr int kDrainResume = 12;        // ... and, once the slow kernel took over, until they are back at or below this
-constexpr int kQlenWindow = 12;         // ring entries (steps) a decision looks at
+constexpr int kQlenRing = 288;           // one report per period of a day
+constexpr int kDrainMaxQueue = 16;      // in-kernel drain only while NO step of the last day queued more than this
 
 struct evc_engine {
     int device = 0;
@@ -76,17 +75,17 @@ struct evc_engine {
     NetTables* d_tables = nullptr;
     int* d_slow_count = nullptr;  // [2]: queue length per step parity
     int* d_slow_list = nullptr;
-    // Drain mode (who solves what the streaming kernel queues): normally every workgroup of the lean compact
-    // streaming kernel solves the environments it queued itself and NO slow kernel is launched (saves the ~2 us
-    // an almost always empty dependent launch costs per step; solves of different workgroups run side by side).
-    // Once steps queue more than a few dozen environments — several per workgroup would serialise — the slow
-    // kernel takes over (one workgroup per queued environment) until the queues are short again.  The decision
-    // reads the per-step totals the kernels report into a page-locked ring: stale by however far the host runs
-    // ahead, which only costs speed, never correctness — either drainer finishes every queued step.
+    // Drain mode (who solves what the streaming kernel queues): on a workload whose steps queue at most a few
+    // dozen environments every workgroup of the lean compact streaming kernel solves the ones it queued itself
+    // and NO slow kernel is launched (saves the ~2 us an almost always empty dependent launch costs per step;
+    // solves of different workgroups run side by side).  Where steps queue more — several per workgroup would
+    // serialise — the slow kernel runs (one workgroup per queued environment).  The decision reads the per-step
+    // totals the kernels report into a page-locked ring of one day: stale by however far the host runs ahead,
+    // which only costs speed, never correctness — either drainer finishes every queued step.
     int* h_qlen = nullptr;        // [kQlenRing] host view
     int* d_qlen = nullptr;        // device address of the same memory
     unsigned long long step_index = 0;
-    bool solver_mode = false;
+    bool warmed = false;          // both lean streaming copies have been launched once
     int drain_override = -1;      // EVC_DRAIN=0/1 forces a mode (measurements)
     int* d_idbuf = nullptr;       // reset ids/slots staging [2N]
     double* d_metrics = nullptr;  // [8]
@@ -310,13 +309,13 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     // drain mode (see evc_engine): the lean compact streaming kernel can drain short queues itself
     bool drain = false;
     if (e->P.project && e->use_quad && e->compact && !dbg && e->h_qlen) {
-        int recent = 0;                                  // longest queue among the last kQlenWindow reports
-        for (int i = 1; i <= kQlenWindow; i++) {
-            const int v = ((volatile int*)e->h_qlen)[(e->step_index + kQlenRing - i) % kQlenRing];
-            if (v > recent) recent = v;
-        }
-        e->solver_mode = e->solver_mode ? recent > kDrainResume : recent > kDrainMaxQueue;
-        drain = !e->solver_mode;
+        // longest queue among the last day's reports; slots no kernel has written yet hold INT_MAX, so an engine
+        // starts with the slow kernel and only drops it after a whole day of short queues (the host runs ahead of
+        // the GPU by many steps: a rule that followed the last few reports switched too late on a day whose
+        // queues ramp up within a few periods — 107 instead of 78 us per step on JPL's GMM days, measured)
+        int recent = 0;
+        for (int i = 0; i < kQlenRing; i++) { const int v = ((volatile int*)e->h_qlen)[i]; if (v > recent) recent = v; }
+        drain = recent <= kDrainMaxQueue;
         const long long quads_per_wave = (((long long)e->P.N + 3) / 4 + 4LL * e->quad_grid - 1) / (4LL * e->quad_grid);
         if (quads_per_wave * 16 > kDrainListMax) drain = false;        // a workgroup's list must hold every env it steps
         if (e->drain_override >= 0) drain = e->drain_override != 0;
@@ -335,6 +334,16 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
 #define EVC_LAUNCH_(KDBG, KFAST, KDRAIN, KPLAIN, GRID, W)                                           \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \
+            if (!dbg && !e->warmed && e->use_quad && e->compact) {                                 \
+                /* first lean step: run BOTH copies once on zero environments, so that neither's first  \
+                   launch (code load, scratch sizing: milliseconds) lands in a later mode switch */      \
+                Params pw = e->P;                                                                  \
+                pw.N = 0;                                                                          \
+                pw.host_qlen = nullptr;                                                            \
+                hipLaunchKernelGGL(KDRAIN, dim3(GRID), dim3(256), 0, e->stream, pw, io);           \
+                hipLaunchKernelGGL(KFAST, dim3(GRID), dim3(256), 0, e->stream, pw, io);            \
+                e->warmed = true;                                                                  \
+            }                                                                                      \
             if (dbg) launch(KDBG, GRID, 256, 0);                                                   \
             else if (drain) launch(KDRAIN, GRID, 256, 0);                                          \
             else launch(KFAST, GRID, 256, 0);                                                      \
@@ -550,7 +559,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     compute_grids(e);
     // queue lengths reported to the host (drain mode); without it the slow kernel simply always runs
     if (hipHostMalloc((void**)&e->h_qlen, sizeof(int) * kQlenRing, hipHostMallocMapped) == hipSuccess) {
-        memset(e->h_qlen, 0, sizeof(int) * kQlenRing);
+        for (int i = 0; i < kQlenRing; i++) e->h_qlen[i] = INT_MAX;
         if (hipHostGetDevicePointer((void**)&e->d_qlen, e->h_qlen, 0) != hipSuccess) e->d_qlen = nullptr;
     } else {
         e->h_qlen = nullptr;
