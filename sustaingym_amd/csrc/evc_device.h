@@ -99,6 +99,7 @@ struct Params {
     // simple rows only are projected in closed form (water-filling) inside the streaming kernel.
     double class_cap[EVC_MAX_GROUPS];
     unsigned simple_rows;                           // bit c set: row c is simple
+    double prox_step;                               // 1 / (Gershgorin bound on lambda_max(B B')): step of the solver's proximal-gradient safeguard
     // persistent state
     double* rem;             // [N][n] remaining demand (kWh) of the plugged EV
     int* depest;             // [N][n] departure (low 16) | est_departure (high 16)

@@ -201,6 +201,25 @@ int build_tables(const evc_network_desc* net, Params& P, NetTables& T) {
         const double ryp = (r - slack[c] - round_slack[c]) * (1.0 - 1e-4) * 8.0;
         T.thr_yp2[c] = ryp > 0.0 ? (float)(ryp * ryp) : 0.0f;
     }
+    // step of the slow path's proximal-gradient safeguard (evc_solver.h): B = rows [Re; Im] of A~ in station
+    // space, (B B')_ab = sum_g n_g M_a[g] M_b[g]; lambda_max <= largest absolute row sum (Gershgorin)
+    {
+        double bound = 0.0;
+        for (int a = 0; a < 2 * m; a++) {
+            double row = 0.0;
+            for (int b = 0; b < 2 * m; b++) {
+                double dot = 0.0;
+                for (int g = 0; g < P.G; g++) {
+                    const double ma = (a & 1) ? T.Mim[g][a >> 1] : T.Mre[g][a >> 1];
+                    const double mb = (b & 1) ? T.Mim[g][b >> 1] : T.Mre[g][b >> 1];
+                    dot += (double)__builtin_popcountll(P.group_mask[g]) * ma * mb;
+                }
+                row += std::fabs(dot);
+            }
+            bound = std::max(bound, row);
+        }
+        P.prox_step = bound > 0.0 ? 1.0 / bound : 0.0;
+    }
     // simple rows: all non-zero coefficients inside one station class -> a cap on that class sum
     P.simple_rows = 0u;
     for (int g = 0; g < EVC_MAX_GROUPS; g++) P.class_cap[g] = HUGE_VAL;

@@ -227,6 +227,60 @@ __device__ __forceinline__ void solver_small(SolverLds& L, int lane, double rhs)
     SOLVER_SYNC();
 }
 
+// Safeguard for the Newton ascent (it can stall where many overlapping rows make the multipliers non-unique:
+// 2 of 30 random networks in tests/soak/network_fuzz.py): accelerated proximal gradient on the same dual.
+// q(z) = f(z) - sum_c r_c ||z_c||, f(z) = min_{0<=y<=h} 1/2||y-b||^2 + z.By concave with gradient B y(z), Lipschitz
+// with L <= P.prox_step^-1 (Gershgorin on B B', evc_engine.hip build_tables); the prox of the norm term is a block
+// soft-threshold.  FISTA with gradient restart — globally convergent, 50-550 passes in practice
+// (tools/proj_fallback_proto.py) — and only entered when the Newton did not deliver.  z = L.z, momentum point = L.zt.
+// Leaves the pass state of the returned z; returns true if the Newton's KKT test is met.
+__device__ __forceinline__ bool solver_proximal_gradient(const Params& P, SolverLds& L, SolverLane& ln, int lane) {
+    const int m = P.m;
+    const double t = P.prox_step;
+    if (!(t > 0.0)) return false;
+    if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; L.zt[lane][0] = 0.0; L.zt[lane][1] = 0.0; }
+    SOLVER_SYNC();
+    double theta = 1.0;
+    for (int k = 0; k < 50000; k++) {             // bounded: ~20 ms for one environment at worst
+        solver_pass(P, L, ln, lane, L.zt);
+        double zn0 = 0.0, zn1 = 0.0, z0 = 0.0, z1 = 0.0, rs = 0.0;
+        if (lane < m) {
+            const double v0 = L.zt[lane][0], v1 = L.zt[lane][1];
+            const double u0 = v0 + t * L.w[lane][0], u1 = v1 + t * L.w[lane][1];
+            const double nu = sqrt(u0 * u0 + u1 * u1);
+            const double shrink = nu > 0.0 ? fmax(1.0 - t * L.net.mag[lane] / nu, 0.0) : 0.0;
+            zn0 = u0 * shrink; zn1 = u1 * shrink;
+            z0 = L.z[lane][0]; z1 = L.z[lane][1];
+            rs = (zn0 - z0) * (v0 - zn0) + (zn1 - z1) * (v1 - zn1);
+        }
+        const double restart = wave_sum_f64(rs);
+        double theta_n = 1.0, beta = 0.0;
+        if (!(restart > 0.0)) {
+            theta_n = 0.5 * (1.0 + sqrt(1.0 + 4.0 * theta * theta));
+            beta = (theta - 1.0) / theta_n;
+        }
+        theta = theta_n;
+        if (lane < m) {
+            L.zt[lane][0] = zn0 + beta * (zn0 - z0); L.zt[lane][1] = zn1 + beta * (zn1 - z1);
+            L.z[lane][0] = zn0; L.z[lane][1] = zn1;
+        }
+        SOLVER_SYNC();
+        if ((k & 15) == 15) {
+            solver_pass(P, L, ln, lane, L.z);
+            double g0, g1, nz, nw;
+            row_gradient(L, m, lane, L.z, g0, g1, nz, nw);
+            bool bad = false;
+            if (lane < m) {
+                const double rc = L.net.mag[lane];
+                bad = nz > 0.0 ? sqrt(g0 * g0 + g1 * g1) / rc > Consts::PROJ_TOL_KKT : nw / rc - 1.0 > Consts::PROJ_TOL;
+            }
+            if (__ballot(bad) == 0ull) return true;
+        }
+    }
+    solver_pass(P, L, ln, lane, L.z);
+    return false;
+}
+
 #ifndef EVC_SOLVE_ENV_INLINE
 #define EVC_SOLVE_ENV_INLINE __forceinline__
 #endif
@@ -428,7 +482,10 @@ __device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io
     SOLVER_STAT(9, c2 - c1); SOLVER_STAT(10, t_head); SOLVER_STAT(11, t_build); SOLVER_STAT(12, t_chol); SOLVER_STAT(13, t_ls);
     SOLVER_STAT(2, n_iter); SOLVER_STAT(3, n_trial); SOLVER_STAT(4, n_act); SOLVER_STAT(5, n_iter >= 20 ? 1 : 0);
     SOLVER_STAT(6, n_act == 1 ? 1 : 0); SOLVER_STAT(7, (!converged && !last_ok) ? 1 : 0);
-    if (!converged && !last_ok) r.status |= EVC_STATUS_PROJ_NOCONV;
+    if (!converged && !last_ok) {                 // rare: the Newton stalled — globally convergent fallback
+        converged = solver_proximal_gradient(P, L, ln, lane);
+        if (!converged) r.status |= EVC_STATUS_PROJ_NOCONV;
+    }
     // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
     // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
     double y = ln.y;
