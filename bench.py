@@ -476,6 +476,7 @@ def main():
         gen_ms = e0.elapsed_time(e1) / 10
         episode_generation = {'kernel': 'evc::generate_kernel', 'episodes': w.P, 'ms': round(gen_ms, 4),
                               'episodes_per_s': round(w.P / gen_ms * 1e3, 1)}
+    tie = w.eng.read_metrics()
     w.close()
     if rank == 0 and world == 1 and not args.no_secondary:
         secondary = {}
@@ -514,7 +515,11 @@ def main():
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'episode_generation': episode_generation,
             'episode_metrics': {'profit': float(total[0]), 'carbon_cost': float(total[1]),
                                 'excess_charge': float(total[2]), 'episodes_finished': float(total[4]),
-                                'envs_with_status': float(total[5])},
+                                'envs_with_status': float(total[5]),
+                                # reach of the tie snap on rank 0: values a projection solver moved, and how
+                                # many of them lay within 1e-6 A of a rounding boundary before the snap
+                                'solver_moved_values': float(tie['solver_moved_values']),
+                                'tie_snap_near_boundary': float(tie['tie_snap_near_boundary'])},
             'secondary': secondary,
         }
         print(json.dumps(line))

@@ -286,7 +286,11 @@ int evc_clear_status(evc_engine* e);
 /* Device-side reduction of the metrics the multi-GPU all-gather carries:
  * out_host[8] = sum profit, sum carbon_cost, sum excess_charge (of running episodes),
  * env-steps executed since create, episodes finished since create, envs with non-zero
- * status, 0, 0. */
+ * status; [6] = values a projection solver moved (and tie-snapped to the 2^-16 A grid)
+ * since create, [7] = those of them that lay within 1e-6 A of a rounding boundary of env.py:373-378
+ * before the snap (the reach of the snap: only there could another solver's rounding differ).  Counted by the
+ * iterative slow path always and by the in-row water-filling only on steps with pilots / rates / projected
+ * outputs requested (the counting costs the lean streaming kernel 1 us per step). */
 int evc_read_metrics(evc_engine* e, double* out_host);
 
 /* Number of environments the most recent evc_step handed to the iterative/exact projection kernel

@@ -342,12 +342,15 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
                 // (relaxation argument); what remains violated goes to the slow kernel.
                 bool fill = undecided && cap_viol != 0u;
                 if (__builtin_expect(__ballot(fill) != 0ull, 0)) {
+                    bool slot_cc[kSlots];
+#pragma unroll
+                    for (int c = 0; c < kSlots; c++) slot_cc[c] = valid[c] && (st_info[st[c]] >> 7) != 0u;
                     for (int g = 0; g < P.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
-                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y);
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr);
                     }
                     unsigned cv2;
-                    const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, 1e-6), row);
+                    const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, P.snap_tol), row);
                     anyviol = anyviol && !(fill && !still);
                 }
                 const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel

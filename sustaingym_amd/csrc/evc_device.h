@@ -99,6 +99,8 @@ struct Params {
     // simple rows only are projected in closed form (water-filling) inside the streaming kernel.
     double class_cap[EVC_MAX_GROUPS];
     unsigned simple_rows;                           // bit c set: row c is simple
+    double snap_tol;                                // row tolerance after the tie snap: PROJ_TOL + what snapping can add to a row / cap
+    int* tie_counters;                              // [kTieSlots][2] tie_snap_counted
     double prox_step;                               // 1 / (Gershgorin bound on lambda_max(B B')): step of the solver's proximal-gradient safeguard
     // persistent state
     double* rem;             // [N][n] remaining demand (kWh) of the plugged EV
@@ -316,6 +318,37 @@ struct Philox {
 __device__ __forceinline__ double tie_snap(double y, double h) {
     const double s = (rint(y * Consts::TIE_SNAP - Consts::TIE_OFFSET) + Consts::TIE_OFFSET) / Consts::TIE_SNAP;
     return fmin(fmax(s, 0.0), h);
+}
+
+// Reach of the tie snap, counted (evc_read_metrics): counters[0] = values a projection solver moved (and snapped),
+// counters[1] = those that sat within 1e-6 A of a rounding boundary of env.py:373-378 BEFORE the snap — the
+// only ones for which an interior-point answer of the reference's accuracy (~1e-8 relative) could round to the
+// other pilot.  Counted by the slow path and by the streaming kernels WITH per-station debug outputs; the lean
+// streaming kernels pass no counters (the counting code alone cost them 1 us per step, measured).
+constexpr int kTieSlots = 256;
+__device__ __forceinline__ double tie_snap_counted(double y, double h, bool is_cc, int* counters) {
+#ifdef EVC_ABL_NO_TIE_COUNT       /* ablation builds only: cost of the counting */
+    counters = nullptr;
+#endif
+    const double eps = 1e-6;
+    bool near;
+    if (is_cc) {
+        const double u = y * 0.125;
+        near = fabs(u - floor(u) - 0.5) < eps * 0.125;
+    } else {
+        near = y > 6.0 - eps && (fabs(y - floor(y) - 0.5) < eps || fabs(y - 6.0) < eps);
+    }
+    if (counters) {
+        // one atomic per call site and wavefront, spread over kTieSlots counter pairs: a congested midday moves
+        // tens of thousands of values per step, and single-address atomics serialise
+        const unsigned long long movers = __ballot(true), nears = __ballot(near);
+        if (__lane_id() == (unsigned)__builtin_ctzll(movers)) {
+            int* slot = counters + 2 * (blockIdx.x & (kTieSlots - 1));
+            atomicAdd(slot, __popcll(movers));
+            if (nears) atomicAdd(slot + 1, __popcll(nears));
+        }
+    }
+    return tie_snap(y, h);
 }
 
 // env.py:366-378: normalised action -> EVSE-legal pilot (A).  y = 32 * action (float64).

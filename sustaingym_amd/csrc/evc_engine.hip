@@ -75,6 +75,7 @@ struct evc_engine {
     NetTables* d_tables = nullptr;
     int* d_slow_count = nullptr;  // [2]: queue length per step parity
     int* d_slow_list = nullptr;
+    int* d_tie = nullptr;         // Params::tie_counters
     // Drain mode (who solves what the streaming kernel queues): on a workload whose steps queue at most a few
     // dozen environments every workgroup of the lean compact streaming kernel solves the ones it queued itself
     // and NO slow kernel is launched (saves the ~2 us an almost always empty dependent launch costs per step;
@@ -129,7 +130,7 @@ void free_all(evc_engine* e) {
                     e->d_nsess, e->d_slot_moer,
                     e->d_slow_count, e->d_slow_list, e->d_idbuf, e->d_metrics, e->d_act, e->d_act_f32, e->d_obs,
                     e->d_reward, e->d_term, e->d_breakdown, e->d_final, e->d_pilots, e->d_rates,
-                    e->d_proj, e->d_maxprofit, e->d_gen};
+                    e->d_proj, e->d_maxprofit, e->d_gen, e->d_tie};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ev : e->ev)
@@ -219,6 +220,18 @@ int build_tables(const evc_network_desc* net, Params& P, NetTables& T) {
             bound = std::max(bound, row);
         }
         P.prox_step = bound > 0.0 ? 1.0 / bound : 0.0;
+    }
+    // Rows are re-verified after the tie snap (2^-16 A grid: a value moves by at most 2^-17 A): the snap can add
+    // sum_g |A_cg| n_g 2^-17 A to row c and n_g 2^-17 A to the sum of class g
+    {
+        double worst = 0.0;
+        for (int c = 0; c < m; c++) {
+            double load = 0.0;
+            for (int g = 0; g < P.G; g++)
+                load += std::fabs(net->constraint_matrix[c * n + rep[g]]) * __builtin_popcountll(P.group_mask[g]);
+            worst = std::max(worst, load * (1.0 / 131072.0) / net->magnitudes[c]);
+        }
+        P.snap_tol = Consts::PROJ_TOL + worst;
     }
     // simple rows: all non-zero coefficients inside one station class -> a cap on that class sum
     P.simple_rows = 0u;
@@ -515,6 +528,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(dmalloc(&e->d_maxprofit, (size_t)bank_slots));
     A(dmalloc(&e->d_slow_count, 2));
     A(dmalloc(&e->d_slow_list, N));
+    A(dmalloc(&e->d_tie, 2 * kTieSlots));
     A(dmalloc(&e->d_idbuf, 2 * N));
     A(dmalloc(&e->d_metrics, 8));
     if (err != hipSuccess) {
@@ -534,6 +548,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(hipMemset(e->d_moer_hist, 0, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS));
     A(hipMemset(e->d_moer_obs, 0, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
     A(hipMemset(e->d_slow_count, 0, 2 * sizeof(int)));
+    A(hipMemset(e->d_tie, 0, 2 * kTieSlots * sizeof(int)));
     A(hipMemset(e->d_slow_list, 0xff, sizeof(int) * N));
     A(copy_h2d(e->d_tables, &T, sizeof(T), e->stream));
     for (auto& ev : e->ev) A(hipEventCreate(&ev));
@@ -554,7 +569,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     P.rem = e->d_rem; P.depest = e->d_depest; P.scal = e->d_scal; P.acc = e->d_acc;
     P.sessions = e->d_sessions; P.requested = e->d_requested; P.n_sessions = e->d_nsess;
     P.slot_moer_day = e->d_slot_moer; P.moer_hist = e->d_moer_hist; P.moer_obs = e->d_moer_obs;
-    P.tables = e->d_tables; P.slow_count = e->d_slow_count; P.slow_list = e->d_slow_list;
+    P.tables = e->d_tables; P.slow_count = e->d_slow_count; P.slow_list = e->d_slow_list; P.tie_counters = e->d_tie;
     {   // window over the arrays the compact streaming kernel reads through one descriptor (struct Win)
         struct Arr { const void* p; size_t bytes; unsigned* off; };
         Params& Q = e->P;

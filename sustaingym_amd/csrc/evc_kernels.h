@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void step_kernel(Params P, StepIO io) {
                         unsigned cv2;
                         if (exact_rows(P, net, ln, lane, yw, cv2) == 0ull) {
                             // tie snap of solver-moved values
-                            if (yw != y) yw = tie_snap(yw, h);
+                            if (yw != y) yw = tie_snap_counted(yw, h, ln.is_cc, P.tie_counters);
                             y = yw;
                             solved = true;
                         }
@@ -603,6 +603,12 @@ __global__ __launch_bounds__(256) void metrics_kernel(Params P, double* out) {
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&out[0], s0); atomicAdd(&out[1], s1); atomicAdd(&out[2], s2);
         atomicAdd(&out[4], eps); atomicAdd(&out[5], bad);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double moved = 0.0, near = 0.0;
+        for (int i = 0; i < kTieSlots; i++) { moved += (double)P.tie_counters[2 * i]; near += (double)P.tie_counters[2 * i + 1]; }
+        out[6] = moved;
+        out[7] = near;
     }
 }
 

@@ -112,7 +112,7 @@ __device__ __forceinline__ bool quad_exact_rows(const Params& P, const LdsNet& n
 __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gid)[kSlots],
                                                const float (&act)[kSlots], const int (&dep)[kSlots],
                                                const double (&rem)[kSlots], double cap,
-                                               double (&y)[kSlots]) {
+                                               double (&y)[kSlots], const bool (&is_cc)[kSlots], int* counters) {
     // target b and cap h of every slot, once (slots that are compile-time empty fold away)
     double b[kSlots], h[kSlots];
     bool in_g[kSlots];
@@ -153,7 +153,7 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
         if (on && in_g[j]) {
             const double yw = fmin(fmax(b[j] - nu, 0.0), h[j]);
             // tie snap of solver-moved values
-            y[j] = (yw != fmin(b[j], h[j])) ? tie_snap(yw, h[j]) : yw;
+            y[j] = (yw != fmin(b[j], h[j])) ? tie_snap_counted(yw, h[j], is_cc[j], counters) : yw;
         }
     }
 }
@@ -322,11 +322,11 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
                     // slow kernel recomputes them from the stored state
                     for (int g = 0; g < P.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
-                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y);
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, st_cc, DBG ? P.tie_counters : nullptr);
                     }
                     unsigned cv2;
-                    // re-verify every row on the snapped values (snapping moves a class sum by < n 2^-17 A)
-                    const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, 1e-6), row);
+                    // re-verify every row on the snapped values: Params::snap_tol = PROJ_TOL + the most the snap can add to a row
+                    const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, P.snap_tol), row);
                     anyviol = anyviol && !(fill && !still);
                 }
                 const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel

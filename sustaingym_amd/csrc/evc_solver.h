@@ -489,7 +489,7 @@ __device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io
     // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
     // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
     double y = ln.y;
-    if (y != fmin(ln.b, ln.h)) y = tie_snap(y, ln.h);
+    if (y != fmin(ln.b, ln.h)) y = tie_snap_counted(y, ln.h, lnet.is_cc, P.tie_counters);
     finish_step<WORDS>(P, io, L.net, lnet, env, lane, y, clamped, cur.acc, false, r);
     SOLVER_STAT(14, SOLVER_CLK() - c2);
     SOLVER_SYNC();

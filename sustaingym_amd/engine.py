@@ -423,7 +423,8 @@ class StepEngine:
         out = np.zeros(8, np.float64)
         check(self.lib.evc_read_metrics(self.handle, _np_ptr(out)), 'evc_read_metrics')
         return {'profit': out[0], 'carbon_cost': out[1], 'excess_charge': out[2],
-                'env_steps': out[3], 'episodes_finished': out[4], 'envs_with_status': out[5]}
+                'env_steps': out[3], 'episodes_finished': out[4], 'envs_with_status': out[5],
+                'solver_moved_values': out[6], 'tie_snap_near_boundary': out[7]}
 
     def last_slow_count(self) -> int:
         c = C.c_int32()

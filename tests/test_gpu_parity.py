@@ -136,6 +136,11 @@ def test_busy_network_projection_active(caltech):
     assert not (status & 2).any(), 'oracle projection failed to converge'
     sc = eng.env_scalars()
     assert not (sc['status'] & 2).any(), 'HIP projection failed to converge'
+    # reach of the tie snap: the solvers moved many values; those within 1e-6 A of a rounding
+    # boundary before the snap are the only ones an eps-accurate interior-point answer could round differently
+    met = eng.read_metrics()
+    assert met['solver_moved_values'] > 1000 and 0 <= met['tie_snap_near_boundary'] <= met['solver_moved_values']
+    print(f"tie snap: {met['tie_snap_near_boundary']:.0f} of {met['solver_moved_values']:.0f} solver-moved values near a rounding boundary")
     eng.close()
 
 
