@@ -305,6 +305,38 @@ def secondary_gmm(site, dev_index, battery) -> dict:
     return rec
 
 
+def secondary_tie_snap(dev_index, battery) -> dict:
+    """Reach of the tie snap on the reference's own episode distribution: one whole GMM day of
+    16 384 Caltech environments through the kernels WITH per-station outputs (they count every value a
+    projection solver moves and how many of those lay within 1e-6 A of a rounding boundary before the snap)."""
+    import torch
+    from sustaingym_amd.engine import StepEngine
+    from sustaingym_amd.event_generation import gmm_device_tables
+    from sustaingym_amd.network import site_str_to_site
+    from sustaingym_amd.synthetic import synthetic_moer
+    net = site_str_to_site('caltech')
+    N = 16384
+    eng = StepEngine(net, N, project_action=True, autoreset=True, device=dev_index, bank_slots=N, max_sessions=128,
+                     moer_days=32, debug_outputs=True, charge_calculation=battery)
+    eng.upload_moer(synthetic_moer(32, seed=7))
+    eng.upload_gmm(dict(gmm_device_tables('caltech', 'Summer 2019'), num_days=32))
+    eng.generate_episodes(0, N, 4242, 0)
+    eng.reset()
+    g = torch.Generator(device=torch.device('cuda', dev_index))
+    g.manual_seed(77)
+    ring = [torch.rand((N, net.num_stations), device=torch.device('cuda', dev_index), generator=g) for _ in range(8)]
+    for t in range(EPISODE):
+        eng.step(ring[t % 8])
+    met = eng.read_metrics()
+    eng.close()
+    pilots = N * EPISODE * net.num_stations
+    return {'workload': f'{N} x 54-station (caltech), one GMM day, projection on, U[0,1) actions',
+            'pilot_values': pilots, 'solver_moved_values': int(met['solver_moved_values']),
+            'within_1e-6A_of_a_rounding_boundary': int(met['tie_snap_near_boundary']),
+            'fraction_of_moved': round(met['tie_snap_near_boundary'] / max(1.0, met['solver_moved_values']), 8),
+            'fraction_of_all_pilots': round(met['tie_snap_near_boundary'] / pilots, 10)}
+
+
 def secondary_multiagent(dev_index, battery) -> dict:
     """BASELINE configs[4]: 8 192 environments x 54 agents.  'view' = zero-copy [N, n, F] broadcast of the flat
     observation (what the reference's multiagent_env.py:114-117 hands out: the same array for every agent);
@@ -483,7 +515,8 @@ def main():
         for name, fn in (('gmm_caltech', lambda: secondary_gmm('caltech', local_rank, args.battery)),
                          ('gmm_jpl', lambda: secondary_gmm('jpl', local_rank, args.battery)),
                          ('multiagent_8192x54', lambda: secondary_multiagent(local_rank, args.battery)),
-                         ('battery_16384', lambda: secondary_battery(local_rank))):
+                         ('battery_16384', lambda: secondary_battery(local_rank)),
+                         ('tie_snap_reach', lambda: secondary_tie_snap(local_rank, args.battery))):
             try:
                 secondary[name] = fn()
             except Exception as exc:          # a secondary record must never cost the headline
