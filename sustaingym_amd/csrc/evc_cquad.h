@@ -75,7 +75,7 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
     const StepIO& io = *(const StepIO*)(ka + kStepIOKernargOffset);
     typedef __attribute__((address_space(3))) CquadLds LdsImage;
     CquadLds& S = *(CquadLds*)(LdsImage*)(size_t)(unsigned)rfl((int)lds);
-    const int lane = (int)(threadIdx.x & 63u);
+    const int lane = (int)__lane_id();            // wave 0 of the workgroup: lane = thread id, without asking the caller for it
     const int count = rfl(S.local_count);
     // the slow path's SolverLds image = the workgroup's LDS from `net` on (CquadLds)
     for (int i = 0; i < count; i++) solve_env<WORDS>(P, io, *reinterpret_cast<SolverLds*>(&S), lane, rfl(S.local_list[i]));

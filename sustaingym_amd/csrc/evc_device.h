@@ -343,7 +343,11 @@ __device__ __forceinline__ double tie_snap_counted(double y, double h, bool is_c
         // tens of thousands of values per step, and single-address atomics serialise
         const unsigned long long movers = __ballot(true), nears = __ballot(near);
         if (__lane_id() == (unsigned)__builtin_ctzll(movers)) {
-            int* slot = counters + 2 * (blockIdx.x & (kTieSlots - 1));
+            // slot from the hardware id (SIMD / pipe / CU bits of HW_REG_HW_ID), not from blockIdx: the slow path is
+            // also reached through a call (evc_cquad.h), and a callee that wants workgroup ids makes its caller keep
+            // them alive through the whole streaming loop
+            const unsigned hw = (unsigned)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (7 << 11));
+            int* slot = counters + 2 * (hw & (kTieSlots - 1));
             atomicAdd(slot, __popcll(movers));
             if (nears) atomicAdd(slot + 1, __popcll(nears));
         }

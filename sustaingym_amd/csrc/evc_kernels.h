@@ -84,7 +84,9 @@ struct EnvLoads {
     double acc;       // breakdown accumulator (lanes < 3)
 };
 
-__device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& io, int env, int lane) {
+// wave_in_block: which of the workgroup's (up to 4) wavefronts calls; -1 = derive it from the thread id (the slow path, always
+// wave 0, says so: it is also reached through a call whose callee should not need work-item ids from its caller)
+__device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& io, int env, int lane, int wave_in_block = -1) {
     EnvLoads L;
     const unsigned n = (unsigned)P.n, ul = (unsigned)lane;
     L.s0 = P.scal[2 * env];
@@ -93,7 +95,7 @@ __device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& i
         // entries -> stations: every entry announces its lane at its station's cell, then each
         // station lane pulls the entry's words with a lane gather (ds_bpermute)
         __shared__ int entry_of[4][kWave];
-        int* cell = entry_of[threadIdx.x >> 6];
+        int* cell = entry_of[wave_in_block >= 0 ? wave_in_block : (int)(threadIdx.x >> 6)];
         const unsigned A = (unsigned)(rfl(L.s1.z) >> kCountShift) & 0x7fu;
         const double rem_e = buf_ld_f64(row_rsrc(P.rem + (size_t)env * n, A * 8u), ul * 8u);
         const unsigned w_e = buf_ld_u32(row_rsrc(P.depest + (size_t)env * n, A * 4u), ul * 4u);

@@ -294,7 +294,7 @@ __device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io
     SolverLane ln;
     ln.gid = lnet.gid;
     [[maybe_unused]] long long c0 = SOLVER_CLK();
-    const EnvLoads cur = issue_loads(P, io, env, lane);
+    const EnvLoads cur = issue_loads(P, io, env, lane, 0);
     EnvRegs r;
     unpack_env(cur, r);
     bool clamped;
