@@ -84,12 +84,16 @@ __device__ __forceinline__ void solver_pass(const Params& P, SolverLds& L, Solve
         is_free = (v > 0.0) && (v <= ln.h) && (ln.h > 0.0);
     }
     const unsigned long long free_mask = __ballot(is_free);
-    for (int g = 0; g < G; g++) {
-        const double s = wave_sum_f64(ln.gid == g ? ln.y : 0.0);
-        if (lane == 0) {
-            L.S[g] = s;
-            L.kfree[g] = (double)__popcll(free_mask & P.group_mask[g]);
-        }
+    for (int g0 = 0; g0 < G; g0 += 4) {            // four independent DPP ladders in flight (a lone one is all latency)
+        double s[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) s[u] = wave_sum_f64(ln.gid == g0 + u ? ln.y : 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (lane == 0 && g0 + u < G) {
+                L.S[g0 + u] = s[u];
+                L.kfree[g0 + u] = (double)__popcll(free_mask & P.group_mask[g0 + u]);
+            }
     }
     SOLVER_SYNC();
     if (lane < m) {
@@ -218,6 +222,47 @@ __device__ __forceinline__ void solver_small(SolverLds& L, int lane, double rhs)
         double acc = x[i];
 #pragma unroll
         for (int j = i + 1; j < D; j++) acc -= A[i][j] * x[j];
+        x[i] = acc * inv[i];
+    }
+    double mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; i++) mine = lane == i ? x[i] : mine;
+    if (lane < D) L.dir[lane] = mine;
+    SOLVER_SYNC();
+}
+
+// The same for D = 6, 8 (three or four active rows: the usual case at Caltech's congested midday, where the in-LDS
+// Cholesky took 39 k of a solve's 109 k cycles): the system is symmetric, so only the upper triangle is held
+// (D (D + 1) / 2 doubles) — the multiplier of row i at elimination step k is U[k][i] / U[k][k].
+template <int D>
+__device__ __forceinline__ void solver_small_sym(SolverLds& L, int lane, double rhs) {
+    double U[D][D], x[D], inv[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        x[i] = readlane_f64(rhs, i);
+#pragma unroll
+        for (int j = i; j < D; j++) U[i][j] = L.H[i][j];
+    }
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        double piv = U[k][k];
+        piv = piv < 1e-300 ? 1e-300 : piv;
+        double rc0 = __builtin_amdgcn_rcp(piv);
+        rc0 = rc0 * (2.0 - piv * rc0);
+        inv[k] = rc0 * (2.0 - piv * rc0);
+#pragma unroll
+        for (int i = k + 1; i < D; i++) {
+            const double f = U[k][i] * inv[k];
+#pragma unroll
+            for (int j = i; j < D; j++) U[i][j] -= f * U[k][j];
+            x[i] -= f * x[k];
+        }
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; i--) {
+        double acc = x[i];
+#pragma unroll
+        for (int j = i + 1; j < D; j++) acc -= U[i][j] * x[j];
         x[i] = acc * inv[i];
     }
     double mine = 0.0;
@@ -438,6 +483,8 @@ __device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io
         long long cc = SOLVER_CLK(); t_build += cc - cb;
         if (d == 2) solver_small<2>(L, lane, rhs);          // one active row: the usual case
         else if (d == 4) solver_small<4>(L, lane, rhs);
+        else if (d == 6) solver_small_sym<6>(L, lane, rhs);
+        else if (d == 8) solver_small_sym<8>(L, lane, rhs);
         else solver_cholesky(L, d, lane, rhs);
         const double dd0 = wave_sum_f64(lane < d ? grad_a * L.dir[lane] : 0.0);
 
