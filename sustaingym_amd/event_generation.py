@@ -132,8 +132,8 @@ class MOERLoader:
     def retrieve(self, dt: datetime) -> np.ndarray:
         """load_moer.py:364-377: rows with dt <= index < dt + 1 day + 5 min -> [289, 37].
 
-        Column 0 is the float64 history; columns 1..36 are the forecasts at the float32
-        precision the observation uses (env.py:140,391)."""
+        float64 throughout, like the reference's DataFrame values (``info['moer']``); the engine casts
+        the observation's columns to float32 at upload (env.py:140,390-391)."""
         start = -(-(_epoch(dt) - self._t0) // 300)        # first 5-minute mark >= dt
         if start < 0 or start + 289 > len(self._hist):
             raise ValueError(f'MOER data does not cover {dt}')

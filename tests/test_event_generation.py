@@ -89,7 +89,7 @@ def test_notebook_golden_max_profit(real):
     assert abs(ob.max_profit(table.sessions, table.requested) - 14.45262) < 5e-6
     m = g.get_moer()
     assert np.array_equal(m[:, 0], real['caltech_2_2_moer'][:, 0])
-    assert np.array_equal(m[:, 1:].astype(np.float32), real['caltech_2_2_moer'][:, 1:].astype(np.float32))
+    assert m.dtype == np.float64 and np.array_equal(m, real['caltech_2_2_moer'])       # float64, like the reference's matrix
 
 
 def test_real_traces_unclaimed(real):

@@ -8,7 +8,7 @@ arrays (no reference source, no pickles):
         (absolute times as UTC epoch seconds, LA-local wall-clock fields, station index,
         requested / delivered kWh, claimed flag)  <- data/evcharging/acn_data/{site}/*.csv.gz
   sustaingym_amd/data/moer_SGIP_CAISO_SCE.npz   5-minute MOER history (float64) + 36 forecasts
-        (float32, the precision the observation uses) per default period
+        (float64 like the reference's DataFrame; the engine casts to float32 at upload, env.py:390-391) per default period
         <- data/moer/SGIP_CAISO_SCE_*.csv.gz via the reference's load_moer
   sustaingym_amd/data/gmm_{site}.npz            GMM parameters, daily session counts and
         station usage of the 8 pickled models   <- data/evcharging/gmms/{site}/*.pkl
@@ -84,7 +84,7 @@ def main():
         assert gaps == 0, 'MOER series must be gap-free 5-minute data'
         moer[f't0_{pi}'] = np.int64(t[0])
         moer[f'hist_{pi}'] = np.ascontiguousarray(df.values[:, 0], dtype=np.float64)
-        moer[f'fcst_{pi}'] = np.ascontiguousarray(df.values[:, 1:], dtype=np.float32)
+        moer[f'fcst_{pi}'] = np.ascontiguousarray(df.values[:, 1:], dtype=np.float64)   # MOERLoader.retrieve returns float64 (load_moer.py:364-377)
         print('moer period', pi, df.shape, 'gaps', gaps)
     moer['periods'] = np.array(periods)
     path = os.path.join(OUT, 'moer_SGIP_CAISO_SCE.npz')
