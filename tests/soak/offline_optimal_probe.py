@@ -5,7 +5,9 @@ controller on caltech / 2020-02-01..05-31 / seed 2: reward 10.925368, profit 13.
 excess_charge 0.0, max_profit 14.45262.  max_profit is reproduced exactly (tests/test_event_generation.py).
 This script restates the CURRENT OfflineOptimal formulation (algorithms/evcharging/baselines.py:130-223: LP
 over the true sessions with the true MOER column, here solved with SciPy HiGHS) and realises its plan through
-the oracle: reward 12.081, profit 13.877, carbon 1.796.  The notebook cell predates the current code (its
+the oracle: reward 12.081, profit 13.877, carbon 1.796 with the legacy stepwise battery model, 12.023 / 13.810 / 1.787 with
+acnportal's default continuous one (round 2) — neither is near the recorded row, whose carbon / profit ratio (0.166 vs 0.129)
+says it charged at dirtier hours than any optimum of the current objective would.  The notebook cell predates the current code (its
 other cells use the 4-tuple step / reset(return_info=True) API and a `reward_breakdown = oo.run(...)` that the
 current BaseAlgorithm.run no longer returns), so the recorded row belongs to an older controller formulation;
 it is NOT used as a pin."""

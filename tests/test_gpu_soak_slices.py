@@ -10,15 +10,20 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('drain', ['auto', '0', '1'])
 @pytest.mark.parametrize('site', ['caltech', 'jpl'])
-def test_gmm_days_slice(site):
+def test_gmm_days_slice(site, drain, monkeypatch):
     """2 048 device-generated GMM days (Summer 2019 model) per site, projection on, lean streaming kernel +
-    slow kernel, one whole episode = 590 k env-steps against the oracle: no integer mismatch at all, every
+    slow path (as a kernel of its own, drained inside the streaming kernel, and as the engine decides), one whole episode = 590 k env-steps against the oracle: no integer mismatch at all, every
     demand within 1e-6 and every reward within 1e-9 relative, no EVC_STATUS_PROJ_NOCONV."""
     from sustaingym_amd.engine import StepEngine
     from sustaingym_amd.event_generation import gmm_device_tables
     from sustaingym_amd.network import site_str_to_site
     from sustaingym_amd.synthetic import synthetic_moer
+    # who solves what the streaming kernel queues (DESIGN.md §2): '1' = every workgroup drains its own list inside the
+    # streaming kernel (no slow kernel at all), '0' = the slow kernel, 'auto' = the engine's day-long rule
+    if drain != 'auto':
+        monkeypatch.setenv('EVC_DRAIN', drain)
     net = site_str_to_site(site)
     n, N = net.num_stations, 2048
     tabs = gmm_device_tables(site, 'Summer 2019')
