@@ -95,13 +95,23 @@ __device__ __forceinline__ bool quad_exact_rows(const Params& P, const LdsNet& n
                                                 bool want, unsigned& cap_viol, double tol = Consts::PROJ_TOL) {
     double re = 0.0, im = 0.0;
     cap_viol = 0u;
-    for (int g = 0; g < P.G; g++) {
-        double part = 0.0;
+    for (int g0 = 0; g0 < P.G; g0 += 4) {          // four independent reduction ladders in flight (a lone one is all latency)
+        double S[4];
 #pragma unroll
-        for (int j = 0; j < kSlots; j++) part += (st_gid[j] == g) ? y[j] : 0.0;
-        const double S = row_allreduce_f64(part);
-        if (q < m) { re += net.Mre[g][q] * S; im += net.Mim[g][q] * S; }
-        if (S > P.class_cap[g] * (1.0 + tol)) cap_viol |= 1u << g;
+        for (int u = 0; u < 4; u++) {
+            double part = 0.0;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) part += (st_gid[j] == g0 + u) ? y[j] : 0.0;
+            S[u] = row_allreduce_f64(part);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int g = g0 + u;
+            if (g < P.G) {
+                if (q < m) { re += net.Mre[g][q] * S[u]; im += net.Mim[g][q] * S[u]; }
+                if (S[u] > P.class_cap[g] * (1.0 + tol)) cap_viol |= 1u << g;
+            }
+        }
     }
     return want && q < m && sqrt(re * re + im * im) > net.mag[q] * (1.0 + tol);
 }
