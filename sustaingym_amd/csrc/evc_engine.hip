@@ -865,9 +865,14 @@ int evc_gather_agent_obs(evc_engine* e, const float* obs_dev, const float* delay
                          float* out_dev) {
     if (!e || !obs_dev || !out_dev) return fail(EVC_EINVAL, "evc_gather_agent_obs: null argument");
     if (int rc = bind(e)) return rc;
-    int blocks = e->P.N < 4096 ? e->P.N : 4096;
-    hipLaunchKernelGGL(gather_agent_obs_kernel, dim3(blocks), dim3(256), 0, e->stream, obs_dev,
-                       delayed_obs_dev, out_dev, e->P.N, e->P.n, e->P.F);
+    int blocks = e->P.N < 8192 ? e->P.N : 8192;
+    const bool aligned8 = (((uintptr_t)obs_dev | (uintptr_t)delayed_obs_dev | (uintptr_t)out_dev) & 7u) == 0;
+    if (e->P.F % 2 == 0 && e->P.F / 2 <= 256 && aligned8 && !getenv("EVC_GATHER_GENERIC"))
+        hipLaunchKernelGGL(gather_agent_obs_pairs_kernel, dim3(blocks), dim3(256), 0, e->stream, (const float2*)obs_dev,
+                           (const float2*)delayed_obs_dev, (float2*)out_dev, e->P.N, e->P.n, e->P.F);
+    else
+        hipLaunchKernelGGL(gather_agent_obs_kernel, dim3(blocks), dim3(256), 0, e->stream, obs_dev,
+                           delayed_obs_dev, out_dev, e->P.N, e->P.n, e->P.F);
     HIP_TRY(hipGetLastError());
     return EVC_OK;
 }

@@ -589,6 +589,36 @@ __global__ __launch_bounds__(256) void gather_agent_obs_kernel(const float* __re
     }
 }
 
+// The same for even F (the usual case: F = 2n + k + 2 with k = 36), HBM-write-bound as it should be: a thread owns ONE
+// pair of columns (f, f+1) — its two current and two delayed values sit in registers for the whole environment — and
+// walks the agents: column f belongs to "another agent" for every agent except a == f (demands) / a == f - n
+// (est_departures), so a row element is one compare + select, and every store is a coalesced 8-byte store (rows of
+// F floats are 8-byte aligned).  No per-element division, no per-element source load: 66 -> see DESIGN.md §6.
+__global__ __launch_bounds__(256) void gather_agent_obs_pairs_kernel(const float2* __restrict__ obs,
+                                                                     const float2* __restrict__ delayed,
+                                                                     float2* __restrict__ out, int N, int n, int F) {
+    const int P2 = F >> 1;                          // column pairs per row
+    const int groups = (int)blockDim.x / P2;        // agents handled side by side
+    const int p = (int)threadIdx.x % P2, g = (int)threadIdx.x / P2;
+    if (g >= groups) return;
+    const int f0 = 2 * p, f1 = f0 + 1;
+    // agent for which column f is its OWN entry (-1: never, e.g. the MOER / timestep tail)
+    const int own0 = f0 < n ? f0 : (f0 < 2 * n ? f0 - n : -1), own1 = f1 < n ? f1 : (f1 < 2 * n ? f1 - n : -1);
+    for (int env = blockIdx.x; env < N; env += gridDim.x) {
+        const float2 cur = obs[(size_t)env * P2 + p];
+        float2 old = delayed ? delayed[(size_t)env * P2 + p] : cur;
+        if (own0 < 0) old.x = cur.x;                // columns beyond 2n are never delayed
+        if (own1 < 0) old.y = cur.y;
+        float2* dst = out + (size_t)env * n * P2 + p;
+        for (int a = g; a < n; a += groups) {
+            float2 v;
+            v.x = a == own0 ? cur.x : old.x;
+            v.y = a == own1 ? cur.y : old.y;
+            dst[(size_t)a * P2] = v;
+        }
+    }
+}
+
 // metrics reduction: sums of the running accumulators + status census.
 __global__ __launch_bounds__(256) void metrics_kernel(Params P, double* out) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, bad = 0.0, eps = 0.0;
