@@ -637,7 +637,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             buf_st_v4(r_scal, so == kOob ? kOob : so + 16u, o1);
         }
         };
+#ifdef EVC_ABL_NS1_ONLY      /* ablation builds only (WRONG results beyond 16 EVs per environment): what do the wider copies cost the NS = 1 path? */
+        if (false) {
+#else
         if (__builtin_expect(more, 0)) {
+#endif
             if (__ballot(A > 48u) != 0ull) body(std::integral_constant<int, 4>{});
             else if (__ballot(A > 32u) != 0ull) body(std::integral_constant<int, 3>{});
             else body(std::integral_constant<int, 2>{});
