@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
-os.environ['SUSTAINGYM_AMD_LIB'] = os.path.join(os.getcwd(), 'sustaingym_amd/variants/lib_stats.so')
+os.environ.setdefault('SUSTAINGYM_AMD_LIB', os.path.join(os.getcwd(), 'sustaingym_amd/variants/lib_stats.so'))
 import numpy as np, torch
 from sustaingym_amd import _lib
 from sustaingym_amd.engine import StepEngine
