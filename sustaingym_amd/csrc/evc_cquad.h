@@ -48,7 +48,7 @@ struct CquadLds {
             StationCell obs_img[4][4][64];
             float act_img[4][4][64];    // [wave][row][station] clamped action of this step
         } s;
-        char solver_workspace[sizeof(SolverLds) - sizeof(LdsNet)];
+        SolverWs solver_workspace;
     } u;
     uint4 st_mulw[64];          // per station: 0 / 1 / 65536 multipliers of packed words 0..3
     uint4 st_mulw_hi[64];       // words 4..7
@@ -56,8 +56,6 @@ struct CquadLds {
     int local_count;            // DRAIN: environments this workgroup queued for its own slow path ...
     int local_list[kDrainListMax];   // ... (the engine enables DRAIN only while a workgroup steps at most that many environments)
 };
-static_assert(offsetof(SolverLds, net) == 0, "SolverLds must start with the network tables");
-static_assert(sizeof(SolverLds) <= offsetof(CquadLds, u) + sizeof(CquadLds::Images), "solver workspace must fit the images");
 
 // The in-kernel drain behind a real call (DRAIN kernels): inlined, the slow path's code and live ranges cost
 // the streaming path 5 us per step; with explicit arguments the caller keeps them alive (and spilled) through
@@ -77,8 +75,9 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
     CquadLds& S = *(CquadLds*)(LdsImage*)(size_t)(unsigned)rfl((int)lds);
     const int lane = (int)__lane_id();            // wave 0 of the workgroup: lane = thread id, without asking the caller for it
     const int count = rfl(S.local_count);
-    // the slow path's SolverLds image = the workgroup's LDS from `net` on (CquadLds)
-    for (int i = 0; i < count; i++) solve_env<WORDS>(P, io, *reinterpret_cast<SolverLds*>(&S), lane, rfl(S.local_list[i]));
+    // the slow path works on the workgroup's tables and on the memory of the per-step images (CquadLds::Images)
+    SolverLds L(S.net, S.u.solver_workspace);
+    for (int i = 0; i < count; i++) solve_env<WORDS>(P, io, L, lane, rfl(S.local_list[i]));
 }
 
 // DRAIN: no slow kernel is launched after this one.  Each workgroup keeps the environments whose projection
@@ -312,6 +311,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             }
             bool undecided = live && row_any(maybe, row);
             pilots_screened = !row_any(maybe_p, row);
+#ifdef EVC_ABL_NO_EXACT            /* ablation builds only (wrong results): cost of the exact path on congested days */
+            undecided = false;
+#endif
             if (__builtin_expect(__ballot(undecided) != 0ull, 0)) {
                 // Rare (wave-uniform branch): exact float64 rows; class-cap (pod breaker) violations
                 // are projected in closed form inside the row; anything else goes to the slow kernel.

@@ -263,13 +263,12 @@ void compute_grids(evc_engine* e) {
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks -= blocks % 8;
     e->step_grid = blocks;
-    // Slow kernel: one 64-lane workgroup per queued environment, 24 kB of LDS each -> 6 resident per CU.
-    // On a quiet network the queue is empty (the launch costs ~2 us); on a congested one (most EVSEs
-    // occupied, feeder limits binding) a third of the environments queue up, and 256 workgroups took
-    // 737 us per step where 1536 take ~300 (tools/ab_busy.py).
-    int scap = 6 * e->num_cus;
+    // Slow kernel: four queued environments per 256-thread workgroup (one per wavefront), EVC_SOLVER_WAVES workgroups
+    // resident per CU.  On a quiet network the queue is empty (the launch costs ~2 us); on a congested one (most EVSEs
+    // occupied, feeder limits binding) a third of the environments queue up.
+    int scap = EVC_SOLVER_WAVES * e->num_cus;
     if (const char* s = getenv("EVC_SOLVER_GRID")) scap = atoi(s) > 0 ? atoi(s) : scap;
-    e->solver_grid = e->P.N < scap ? e->P.N : scap;
+    e->solver_grid = (e->P.N + 3) / 4 < scap ? (e->P.N + 3) / 4 : scap;
     // Streaming (quad) kernel: persistent-style grid of 4 workgroups per CU (= the 4 waves/SIMD its
     // register footprint admits), every wave walks several quads.  Measured best on MI355X
     // (tools/ab_caps.py): 1024 workgroups 30-32 us vs 4096 workgroups 35.6 us per step at N = 65 536.
@@ -380,7 +379,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             else if (drain) launch(KDRAIN, GRID, 256, 0);                                          \
             else launch(KFAST, GRID, 256, 0);                                                      \
             if (!drain) {                                                                          \
-                launch(solver_step_kernel<W>, e->solver_grid, 64, 1);                              \
+                launch(solver_step_kernel<W>, e->solver_grid, 256, 1);                              \
                 solver_ran = true;                                                                 \
             }                                                                                      \
         } else {                                                                                   \

@@ -292,21 +292,36 @@ __device__ __forceinline__ void finish_step(const Params& P, const StepIO& io, c
 
     // ---- acnsim event pass at iteration t1: unplug (precedence 0) before plug-in (10) ----
     if (occupied && r.dep <= t1) { r.dep = kEmptyDep; r.est = 0; r.rem = 0.0; }
+    // The sessions from the cursor on, one per lane, in ONE round trip (a morning burst plugs in several EVs in the same
+    // period; fetched one by one each costs two dependent loads); refilled after 63 arrivals.
     while (r.next_arrival <= t1 && r.cursor < r.n_sessions) {
-        const size_t sidx = (size_t)r.slot * P.max_sessions + r.cursor;
-        const evc_session s = P.sessions[sidx];
-        const double rq = P.requested[sidx];
-        const int st = rfl((int)s.station);
-        const bool mine = lane == st;
-        const bool busy = mine && (r.dep != kEmptyDep);
-        if (__ballot(busy) != 0ull) {
-            r.status |= EVC_STATUS_OCCUPIED;          // acnportal: StationOccupiedError
-        } else if (mine) {
-            r.dep = (int)s.departure; r.est = (int)s.est_departure; r.rem = rq;
+        const int base = r.cursor;
+        const size_t s0 = (size_t)r.slot * P.max_sessions + base;
+        const bool inb = base + lane < r.n_sessions;
+        unsigned long long sw = ~0ull;                // arrival -1 -> never reached
+        double rql = 0.0;
+        if (inb) {
+            sw = *reinterpret_cast<const unsigned long long*>(P.sessions + s0 + lane);
+            rql = P.requested[s0 + lane];
         }
-        r.cursor += 1;
-        r.next_arrival = (r.cursor < r.n_sessions)
-            ? rfl((int)P.sessions[sidx + 1].arrival) : kNoArrival;
+        while (r.next_arrival <= t1 && r.cursor < r.n_sessions && r.cursor - base < 63) {
+            const int k = r.cursor - base;
+            const unsigned long long w = (unsigned long long)(unsigned)__shfl((int)(unsigned)sw, k) |
+                                         ((unsigned long long)(unsigned)__shfl((int)(unsigned)(sw >> 32), k) << 32);
+            const double rq = __shfl(rql, k);
+            const int s_departure = (int)(short)(w >> 16), s_est = (int)(short)(w >> 32);
+            const int st = rfl((int)(short)(w >> 48));
+            const bool mine = lane == st;
+            const bool busy = mine && (r.dep != kEmptyDep);
+            if (__ballot(busy) != 0ull) {
+                r.status |= EVC_STATUS_OCCUPIED;          // acnportal: StationOccupiedError
+            } else if (mine) {
+                r.dep = s_departure; r.est = s_est; r.rem = rq;
+            }
+            r.cursor += 1;
+            const int nxt = rfl((int)(short)(unsigned short)__shfl((int)(unsigned)sw, k + 1));   // k + 1 <= 63
+            r.next_arrival = (r.cursor < r.n_sessions) ? nxt : kNoArrival;
+        }
     }
     r.t = t1;
     if (__ballot(clamped && ln.in_net) != 0ull) r.status |= EVC_STATUS_ACTION_CLAMPED;

@@ -21,7 +21,8 @@
 
 namespace evc {
 
-constexpr int kMaxActive = 16;              // rows simultaneously in the Newton system
+constexpr int kMaxActive = 8;               // rows simultaneously in the Newton system (extras wait; beyond that the
+                                            // proximal-gradient safeguard finishes): keeps a workspace at 5 KB
 constexpr int kMaxDim = 2 * kMaxActive;
 constexpr int kSolverMaxIter = 60;
 
@@ -38,8 +39,8 @@ __device__ unsigned long long g_solver_stats[16];
 // executes a wave's ds instructions in issue order), only a compiler barrier.
 #define SOLVER_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-struct SolverLds {
-    LdsNet net;
+// Per-wavefront workspace of one solve; the network tables are shared by the workgroup's wavefronts.
+struct SolverWs {
     double z[EVC_MAX_CONSTRAINTS][2];       // accepted multipliers
     double zt[EVC_MAX_CONSTRAINTS][2];      // trial multipliers
     double w[EVC_MAX_CONSTRAINTS][2];       // M_c S at the last pass
@@ -51,6 +52,23 @@ struct SolverLds {
     double zn[EVC_MAX_CONSTRAINTS];         // |z_c| and z_c / |z_c| of the active rows
     double zh[EVC_MAX_CONSTRAINTS][2];
     int act[kMaxActive];
+};
+// What a solve works on: the tables + its workspace (a view: references into LDS, resolved at compile time).
+struct SolverLds {
+    const LdsNet& net;
+    double (&z)[EVC_MAX_CONSTRAINTS][2];
+    double (&zt)[EVC_MAX_CONSTRAINTS][2];
+    double (&w)[EVC_MAX_CONSTRAINTS][2];
+    double (&nu)[EVC_MAX_GROUPS];
+    double (&S)[EVC_MAX_GROUPS];
+    double (&kfree)[EVC_MAX_GROUPS];
+    double (&H)[kMaxDim][kMaxDim + 1];
+    double (&dir)[kMaxDim];
+    double (&zn)[EVC_MAX_CONSTRAINTS];
+    double (&zh)[EVC_MAX_CONSTRAINTS][2];
+    int (&act)[kMaxActive];
+    __device__ __forceinline__ SolverLds(const LdsNet& n, SolverWs& ws)
+        : net(n), z(ws.z), zt(ws.zt), w(ws.w), nu(ws.nu), S(ws.S), kfree(ws.kfree), H(ws.H), dir(ws.dir), zn(ws.zn), zh(ws.zh), act(ws.act) {}
 };
 
 struct SolverLane {
@@ -326,6 +344,156 @@ __device__ __forceinline__ bool solver_proximal_gradient(const Params& P, Solver
     return false;
 }
 
+// ---- one or two cone rows decide: the Newton in registers ------------------------------------------------------------
+// With the active rows known (R = 1: the most violated row; R = 2: it and the row violated at its optimum) the dual has
+// D = 2R unknowns and every quantity of an iteration is a wave sum over the station lanes: w_a = sum c_a(i) y_i and
+// K_ab = sum_{free i} c_a(i) c_b(i), with c(i) in R^D the rows' coefficients of station i's class.  No LDS exchange, no
+// barriers, the D x D system solved redundantly by every lane — an iteration is a handful of interleaved DPP ladders
+// instead of the general path's five LDS round trips (10 000 cycles per iteration there, measured).  Same start, same
+// Levenberg-Marquardt shift and same KKT target as the general iteration, full steps only; anything irregular (a
+// multiplier that would cross zero, the iteration budget) returns false and the general iteration below takes over
+// from scratch.  On JPL's GMM middays 92 - 99 % of the queue is the R = 1 case, the rest almost all R = 2.
+struct ExactRows { unsigned long long viol; unsigned cap_viol; int worst; };
+// exact float64 rows of schedule y (four class ladders in flight) + the row furthest above its limit
+__device__ __forceinline__ ExactRows exact_rows_worst(const Params& P, const LdsNet& net, const LaneNet& ln, int lane, double y) {
+    double re = 0.0, im = 0.0;
+    ExactRows out{0ull, 0u, -1};
+    for (int g0 = 0; g0 < P.G; g0 += 4) {
+        double S[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) S[u] = wave_sum_f64(ln.gid == g0 + u ? y : 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int g = g0 + u;
+            if (g < P.G) {
+                if (lane < P.m) { re += net.Mre[g][lane] * S[u]; im += net.Mim[g][lane] * S[u]; }
+                if (S[u] > P.class_cap[g] * (1.0 + Consts::PROJ_TOL)) out.cap_viol |= 1u << g;
+            }
+        }
+    }
+    double ratio = 0.0;
+    if (lane < P.m) ratio = sqrt(re * re + im * im) / net.mag[lane];
+    const bool viol = lane < P.m && ratio > 1.0 + Consts::PROJ_TOL;
+    out.viol = __ballot(viol);
+    if (out.viol != 0ull) {
+        // rows live in lanes 0..31: maximum over those by a butterfly, then the first lane that holds it
+        double best = viol ? ratio : 0.0;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) best = fmax(best, __shfl_xor(best, off));
+        best = readlane_f64(best, 0);
+        out.worst = __builtin_ctzll(__ballot(viol && ratio == best) | (1ull << 63));
+    }
+    return out;
+}
+
+template <int R>
+__device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, double h, const int (&rows)[R],
+                                          double (&z)[2 * R], double& yout) {
+    constexpr int D = 2 * R;
+    double cf[D], rmag[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        cf[2 * r] = gid >= 0 ? net.Mre[gid][rows[r]] : 0.0;
+        cf[2 * r + 1] = gid >= 0 ? net.Mim[gid][rows[r]] : 0.0;
+        rmag[r] = net.mag[rows[r]];
+    }
+    double mu = 1e-3;
+    for (int it = 0; it < (R == 1 ? 14 : 24); it++) {
+        double nu = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; a++) nu += cf[a] * z[a];
+        const double v = b - nu;
+        const double y = gid >= 0 ? fmin(fmax(v, 0.0), h) : 0.0;
+        const bool fr = gid >= 0 && (v > 0.0) && (v <= h) && (h > 0.0);
+        double w[D], K[D][D];
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            w[a] = wave_sum_f64(cf[a] * y);
+#pragma unroll
+            for (int e = a; e < D; e++) K[a][e] = wave_sum_f64(fr ? cf[a] * cf[e] : 0.0);
+        }
+        if (it == 0) {
+            // the row without a multiplier: alone, the first-order size along its w; beside an active row, tiny
+            const int a0 = D - 2;
+            const double nw = sqrt(w[a0] * w[a0] + w[a0 + 1] * w[a0 + 1]);
+            if (!(nw > rmag[R - 1])) return false;
+            const double wh0 = w[a0] / nw, wh1 = w[a0 + 1] / nw;
+            double lam = 1e-6;
+            if (R == 1) {
+                const double curv = wh0 * (K[0][0] * wh0 + K[0][1] * wh1) + wh1 * (K[0][1] * wh0 + K[1][1] * wh1);
+                if (curv > 0.0) lam = fmax((nw - rmag[0]) / curv, 1e-6);
+            }
+            z[a0] = lam * wh0;
+            z[a0 + 1] = lam * wh1;
+            continue;
+        }
+        double zh[D], g[D], rn[R];
+        bool conv = true;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const double nz = sqrt(z[2 * r] * z[2 * r] + z[2 * r + 1] * z[2 * r + 1]);
+            zh[2 * r] = z[2 * r] / nz;
+            zh[2 * r + 1] = z[2 * r + 1] / nz;
+            g[2 * r] = w[2 * r] - rmag[r] * zh[2 * r];
+            g[2 * r + 1] = w[2 * r + 1] - rmag[r] * zh[2 * r + 1];
+            rn[r] = rmag[r] / nz;
+            conv = conv && sqrt(g[2 * r] * g[2 * r] + g[2 * r + 1] * g[2 * r + 1]) / rmag[r] <= Consts::PROJ_TOL_KKT;
+        }
+        if (conv) { yout = y; return true; }
+        double B[D][D];
+#pragma unroll
+        for (int a = 0; a < D; a++)
+#pragma unroll
+            for (int e = 0; e < D; e++) B[a][e] = a <= e ? K[a][e] : K[e][a];
+        double tr = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int a = 2 * r;
+            B[a][a] += rn[r] * (1.0 - zh[a] * zh[a]);
+            B[a + 1][a + 1] += rn[r] * (1.0 - zh[a + 1] * zh[a + 1]);
+            B[a][a + 1] -= rn[r] * zh[a] * zh[a + 1];
+            B[a + 1][a] = B[a][a + 1];
+            tr += B[a][a] + B[a + 1][a + 1];
+        }
+        double scale = tr / (double)D;
+        scale = scale < 1e-12 ? 1e-12 : scale;
+#pragma unroll
+        for (int a = 0; a < D; a++) B[a][a] += mu * scale;
+        // Gauss elimination without pivoting (SPD + shift)
+        bool good = true;
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            good = good && B[a][a] > 0.0;
+            const double inv = 1.0 / B[a][a];
+#pragma unroll
+            for (int e = a + 1; e < D; e++) {
+                const double f = B[e][a] * inv;
+#pragma unroll
+                for (int u = a + 1; u < D; u++) B[e][u] -= f * B[a][u];
+                g[e] -= f * g[a];
+            }
+        }
+        double d[D];
+#pragma unroll
+        for (int a = D - 1; a >= 0; a--) {
+            double t = g[a];
+#pragma unroll
+            for (int u = a + 1; u < D; u++) t -= B[a][u] * d[u];
+            d[a] = t / B[a][a];
+        }
+        if (!good) return false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const double t0 = z[2 * r] + d[2 * r], t1 = z[2 * r + 1] + d[2 * r + 1];
+            if (!(t0 * z[2 * r] + t1 * z[2 * r + 1] > 0.0)) return false;     // the row would leave the active set
+        }
+#pragma unroll
+        for (int a = 0; a < D; a++) z[a] += d[a];
+        mu = fmax(mu * 0.25, 1e-12);
+    }
+    return false;
+}
+
 #ifndef EVC_SOLVE_ENV_INLINE
 #define EVC_SOLVE_ENV_INLINE __forceinline__
 #endif
@@ -333,13 +501,13 @@ __device__ __forceinline__ bool solver_proximal_gradient(const Params& P, Solver
 // lane c: constraint row c; lane a: row a of the Newton system).  Shared by the slow kernel and by the
 // streaming kernel's in-kernel queue drain (evc_cquad.h).
 template <int WORDS>
-__device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io, SolverLds& L, int lane, int env) {
+__device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io, SolverLds& L, int lane, int env, int wave_in_block = 0) {
     const int m = P.m, G = P.G;
     const LaneNet lnet = lane_net(P, lane);
     SolverLane ln;
     ln.gid = lnet.gid;
     [[maybe_unused]] long long c0 = SOLVER_CLK();
-    const EnvLoads cur = issue_loads(P, io, env, lane, 0);
+    const EnvLoads cur = issue_loads(P, io, env, lane, wave_in_block);
     EnvRegs r;
     unpack_env(cur, r);
     bool clamped;
@@ -355,15 +523,14 @@ __device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io
     bool settled = false;
     {
         const double y0 = fmin(ln.b, ln.h);
-        unsigned cap_viol;
-        const unsigned long long vrows = exact_rows(P, L.net, lnet, lane, y0, cap_viol);
+        const ExactRows e0 = exact_rows_worst(P, L.net, lnet, lane, y0);
         ln.y = y0;
-        if (vrows == 0ull) {
+        if (e0.viol == 0ull) {
             settled = true;
-        } else if (cap_viol != 0u) {          // caps first, also beside violated multi-class rows
+        } else if (e0.cap_viol != 0u) {       // caps first, also beside violated multi-class rows
             double yw = y0;
             for (int g = 0; g < G; g++)
-                if ((cap_viol >> g) & 1u)
+                if ((e0.cap_viol >> g) & 1u)
                     yw = waterfill_class(lnet.gid == g, ln.b, ln.h, P.class_cap[g], yw);
             unsigned cv2;
             if (exact_rows(P, L.net, lnet, lane, yw, cv2) == 0ull) {
@@ -371,6 +538,41 @@ __device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io
                 settled = true;
             }
         }
+#ifndef EVC_ABL_NO_WAVE_CONE
+        else {
+            // (c) one or two cone rows decide: registers only, see wave_cone; exact if every row and cap holds at the optimum
+            const int r1[1] = {e0.worst};
+            double z1[2] = {0.0, 0.0}, y1 = 0.0;
+            if (wave_cone<1>(L.net, lnet.gid, ln.b, ln.h, r1, z1, y1)) {
+                const ExactRows e1 = exact_rows_worst(P, L.net, lnet, lane, y1);
+                if (e1.viol == 0ull && e1.cap_viol == 0u) {
+                    ln.y = y1;
+                    settled = true;
+                } else if (e1.cap_viol == 0u && e1.worst != e0.worst) {
+                    const int r2[2] = {e0.worst, e1.worst};
+                    double z2[4] = {z1[0], z1[1], 0.0, 0.0}, y2 = 0.0;
+                    if (wave_cone<2>(L.net, lnet.gid, ln.b, ln.h, r2, z2, y2)) {
+                        const ExactRows e2 = exact_rows_worst(P, L.net, lnet, lane, y2);
+                        if (e2.viol == 0ull && e2.cap_viol == 0u) {
+                            ln.y = y2;
+                            settled = true;
+                        } else if (e2.cap_viol == 0u && e2.worst != r2[0] && e2.worst != r2[1]) {
+                            // a third row: rare, but one such environment per step is what the whole launch waits for
+                            const int r3[3] = {r2[0], r2[1], e2.worst};
+                            double z3[6] = {z2[0], z2[1], z2[2], z2[3], 0.0, 0.0}, y3 = 0.0;
+                            if (wave_cone<3>(L.net, lnet.gid, ln.b, ln.h, r3, z3, y3)) {
+                                const ExactRows e3 = exact_rows_worst(P, L.net, lnet, lane, y3);
+                                if (e3.viol == 0ull && e3.cap_viol == 0u) {
+                                    ln.y = y3;
+                                    settled = true;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#endif
     }
     [[maybe_unused]] long long c1 = SOLVER_CLK();
     SOLVER_STAT(8, c1 - c0);
@@ -542,15 +744,25 @@ __device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io
     SOLVER_SYNC();
 }
 
+// Four wavefronts per workgroup, one queued environment each at a time, sharing the network tables in LDS
+// (13 KB + 4 x 5 KB): EVC_SOLVER_WAVES workgroups per CU are resident, i.e. that many solves per SIMD in flight.  A solve
+// is a chain of dependent float64 ladders, LDS round trips, square roots and divides on one wavefront — all latency —
+// so the slow path's throughput is the number of wavefronts in flight (round 1/2: one 64-thread workgroup per solve,
+// 25 KB of LDS and 250 VGPRs each, 6 per CU).
+#ifndef EVC_SOLVER_WAVES
+#define EVC_SOLVER_WAVES 3
+#endif
 template <int WORDS>
-__global__ __launch_bounds__(64) void solver_step_kernel(Params P, StepIO io) {
-    __shared__ SolverLds L;
+__global__ __launch_bounds__(256, EVC_SOLVER_WAVES) void solver_step_kernel(Params P, StepIO io) {
+    __shared__ LdsNet net;
+    __shared__ SolverWs ws[4];
     const int count = rfl(*P.slow_count);
     if (blockIdx.x == 0 && threadIdx.x == 0) queue_begin_drain(P, count);
-    if ((int)blockIdx.x >= count) return;           // nothing queued for this workgroup
-    stage_net(L.net, P);
-    const int lane = threadIdx.x;
-    for (int q = blockIdx.x; q < count; q += gridDim.x) solve_env<WORDS>(P, io, L, lane, rfl(P.slow_list[q]));
+    if ((int)blockIdx.x * 4 >= count) return;       // nothing queued for this workgroup
+    stage_net(net, P);
+    const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
+    SolverLds L(net, ws[wave]);
+    for (int q = blockIdx.x * 4 + wave; q < count; q += gridDim.x * 4) solve_env<WORDS>(P, io, L, lane, rfl(P.slow_list[q]), wave);
 }
 
 }  // namespace evc
