@@ -53,6 +53,7 @@ struct CquadLds {
     uint4 st_mulw[64];          // per station: 0 / 1 / 65536 multipliers of packed words 0..3
     uint4 st_mulw_hi[64];       // words 4..7
     unsigned char st_info[64];  // class id | ClipperCreek << 7
+    int next_quad;              // next of the workgroup's quads nobody has taken yet (see the loop over quads)
     int local_count;            // DRAIN: environments this workgroup queued for its own slow path ...
     int local_list[kDrainListMax];   // ... (the engine enables DRAIN only while a workgroup steps at most that many environments)
 };
@@ -125,6 +126,18 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
     const bool stepwise = P.battery_stepwise != 0;
     const unsigned nquads = (N + 3u) >> 2;
     EnvWalker walk((int)nquads, 4);
+    // The workgroup's quads {walk.first - wv + w + r * stride : w < 4, r} are shared by its four wavefronts: each takes
+    // its own first one, then whichever comes next (an LDS counter).  A wavefront that ran into one of the rare
+    // branches — exact rows, water-filling, a queue push: cold code and scratch reloads, 16 - 30 us per hit measured
+    // on JPL's GMM afternoons, where 0.3 % of the environments took the launch from 40 to 70 us — then takes fewer
+    // quads and its siblings the rest.
+    const int wg_first = walk.first - (int)wv;
+    auto wg_quad = [&](int k) { const int qd = wg_first + (k & 3) + (k >> 2) * walk.stride; return qd < walk.hi ? qd : -1; };
+    auto take_quad = [&]() {
+        int k = 0;
+        if (lane == 0u) k = __hip_atomic_fetch_add(&S.next_quad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return wg_quad(rfl(k));
+    };
     // Raw loads of one quad, issued one iteration ahead (software prefetch): the waves of this kernel
     // spend most of their time waiting for these round trips (SQ_WAIT_ANY = 60 % of the wave cycles).
     struct QuadRaw {
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
     auto issue = [&](int quad_) {
         QuadRaw L;
         const unsigned env_ = (unsigned)quad_ * 4u + row;
-        const bool ev_ = quad_ < walk.hi && env_ < N;
+        const bool ev_ = quad_ >= 0 && env_ < N;
         const unsigned eb_ = env_ * n;
         const unsigned soff = ev_ ? env_ * 32u : kOob;
         L.s0 = buf_ld_v4(r_scal, soff);
@@ -153,8 +166,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
     // The first quad's loads are issued before the LDS tables are built: the two latency chains (network
     // tables from global memory, first state / action rows) overlap instead of following each other —
     // a wave runs only four iterations at N = 65 536, so the prologue is a visible share of the launch.
-    QuadRaw nxt = issue(walk.first);
+    QuadRaw nxt = issue(walk.first < walk.hi ? walk.first : -1);
 
+    if (tid == 0u) S.next_quad = 4;
     if (DRAIN && tid == 0u) {
         S.local_count = 0;
         // the other control block still holds the PREVIOUS step's total (its launch is complete): report it to
@@ -207,7 +221,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         asm volatile("" ::: "memory");
     };
 
-    for (int quad = walk.first; quad < walk.hi; quad += walk.stride) {
+    for (int quad = walk.first < walk.hi ? walk.first : -1; quad >= 0;) {
+        int quad_next = -1;                                  // set where the next quad's loads are issued
         const unsigned env = (unsigned)quad * 4u + row;
         const bool ev = env < N;
         const unsigned ebase = env * n;
@@ -311,6 +326,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             }
             bool undecided = live && row_any(maybe, row);
             pilots_screened = !row_any(maybe_p, row);
+#ifdef EVC_COUNT_UNDECIDED         /* diagnostic builds only: environments the screen leaves undecided, in metrics[7] */
+            if (undecided && q == 0u) atomicAdd(P.tie_counters + 2 * (env & (kTieSlots - 1)) + 1, 1);
+#endif
 #ifdef EVC_ABL_NO_EXACT            /* ablation builds only (wrong results): cost of the exact path on congested days */
             undecided = false;
 #endif
@@ -530,7 +548,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
         // prefetch of the next quad's rows: issued here, after the charge / event section (its 15 VGPRs are not alive through
         // the register-hungry part of the iteration: 184 -> 155 spilled VGPRs, -0.7 us per step with synchronised phases);
         // nothing to fetch after the last quad
-        if (quad + walk.stride < walk.hi) nxt = issue(quad + walk.stride);
+        quad_next = take_quad();
+        if (quad_next >= 0) nxt = issue(quad_next);
         // ---- observation image: demands / est_departures of the surviving entries ----
         auto scatter_obs = [&](int c) {
             if (live && alive[c]) {
@@ -651,6 +670,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cq
             body(std::integral_constant<int, 1>{});
         }
         lds_sync();
+        quad = quad_next;
     }
 
     if (DRAIN) {

@@ -17,10 +17,15 @@ eng.upload_moer(synthetic_moer(tabs['num_days'], seed=7)); eng.upload_gmm(tabs);
 step, out = eng.make_stepper()
 eng.enable_timing(True)
 rows = []
+prev = eng.read_metrics()['tie_snap_near_boundary'] if os.environ.get('UNDEC') else 0
 for i in range(288):
     step(ring[i % 8].data_ptr())
-    a, b = eng.last_step_ms(); rows.append((i, eng.last_slow_count(), a * 1e3, b * 1e3))
+    a, b = eng.last_step_ms()
+    und = 0
+    if os.environ.get('UNDEC'):
+        cur = eng.read_metrics()['tie_snap_near_boundary']; und = cur - prev; prev = cur
+    rows.append((i, eng.last_slow_count(), a * 1e3, b * 1e3, und))
 r = np.array(rows)
 for i in range(0, 288, 6):
     blk = r[i:i + 6]
-    print(f'step {i:3d}: queue max {int(blk[:,1].max()):5d}  main {blk[:,2].mean():6.1f}  solver mean {blk[:,3].mean():6.1f} max {blk[:,3].max():6.1f}')
+    print(f'step {i:3d}: queue max {int(blk[:,1].max()):5d}  main {blk[:,2].mean():6.1f}  solver mean {blk[:,3].mean():6.1f} max {blk[:,3].max():6.1f}  undecided/step {blk[:,4].mean():8.0f}')
