@@ -89,8 +89,13 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
 // one s_barrier.  On congested steps the solves of different workgroups run side by side like the slow
 // kernel's; only several queued environments inside ONE workgroup serialise (the engine falls back to the
 // slow kernel once a step queues more than a few dozen, evc_engine.hip "drain mode").
-template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false>
-__global__ __launch_bounds__(256, DBG ? 2 : EVC_CQUAD_WAVES) void step_kernel_cquad(Params P, StepIO io) {
+//
+// WAVES: wavefronts per SIMD the register allocation is held to.  4 (128 VGPRs) is the streaming choice: the one-slot
+// copy of the iteration body fits, the wide copies (17 - 64 entries per environment) spill.  2 (172 VGPRs, no spill) is
+// the "roomy" form the engine launches on congested stretches of a day, where most wavefronts run a wide copy:
+// JPL's GMM day 45.2 -> 38.9 us per step for this kernel; on the quiet benchmark day it is 5 us slower (evc_engine.hip).
+template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES>
+__global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params P, StepIO io) {
     static_assert(!DRAIN || (PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");
     __shared__ CquadLds S;
     __shared__ double dbg_img[DBG ? 4 : 1][4][64];     // unused (and dropped) in the lean kernels

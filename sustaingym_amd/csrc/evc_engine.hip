@@ -53,6 +53,8 @@ hipError_t dmalloc(T** p, size_t count) {
 
 constexpr bool kDefaultCompact = true;
 constexpr int kQlenRing = 288;           // one report per period of a day
+constexpr int kDrainLookBack = 12, kDrainLookAhead = 36;   // periods of the day around the current one whose reports decide the step's mode
+constexpr int kRoomyMinQueue = 64;      // queue length (around this time of day) from which the 2-waves-per-SIMD form of the lean kernel runs
 constexpr int kDrainMaxQueue = 16;      // in-kernel drain only while NO step of the last day queued more than this
 
 struct evc_engine {
@@ -111,7 +113,8 @@ struct evc_engine {
     unsigned long long env_steps = 0;
     int step_parity = 0;
     int num_cus = 256;
-    int step_grid = 0, solver_grid = 0, quad_grid = 0;
+    int step_grid = 0, solver_grid = 0, quad_grid = 0, roomy_grid = 0;
+    int roomy_override = -1;      // EVC_ROOMY=0/1 forces the choice (measurements, tests)
     unsigned long long policy_seed = 0;   // EVC_ACTION_RANDOM (evc_set_policy_seed)
     unsigned env_id_base = 0;
     bool compact = false;        // state layout (Params::compact)
@@ -279,6 +282,13 @@ void compute_grids(evc_engine* e) {
     if (qblocks >= 8) qblocks -= qblocks % 8;
     if (qblocks < 1) qblocks = 1;
     e->quad_grid = qblocks;
+    {   // the roomy form of the compact kernel: 2 workgroups per CU
+        int rb = (((e->P.N + 3) / 4) + 3) / 4;
+        const int rcap = 2 * e->num_cus;
+        if (rb > rcap) rb = rcap;
+        if (rb >= 8) rb -= rb % 8;
+        e->roomy_grid = rb < 1 ? 1 : rb;
+    }
     // the 4-environments-per-wavefront kernel evaluates constraint row c in lane c of a 16-lane
     // row and addresses whole arrays with 32-bit byte offsets
     const char* kk = getenv("EVC_KERNEL");
@@ -338,7 +348,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     const bool dbg = out->pilots || out->rates || out->projected || out->returns ||
                      action_kind == EVC_ACTION_GREEDY;
     // drain mode (see evc_engine): the lean compact streaming kernel can drain short queues itself
-    bool drain = false;
+    bool drain = false, roomy = false;
     if (e->P.project && e->use_quad && e->compact && !dbg && e->h_qlen) {
         // longest queue among the last day's reports; slots no kernel has written yet hold INT_MAX, so an engine
         // starts with the slow kernel and only drops it after a whole day of short queues (the host runs ahead of
@@ -347,9 +357,26 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         int recent = 0;
         for (int i = 0; i < kQlenRing; i++) { const int v = ((volatile int*)e->h_qlen)[i]; if (v > recent) recent = v; }
         drain = recent <= kDrainMaxQueue;
+        if (!drain && recent != INT_MAX) {
+            // A day with a congested part.  The ring is indexed by the period of the day, so the slots around this step's hold
+            // the last reports for this time of day — today's behind it (as far as the GPU has come), yesterday's ahead.
+            // Quiet there (one hour back, three ahead): drain in the kernel — the nights of a congested day then cost one
+            // launch per step instead of two.  Long queues there: most environments are crowded too, and the lean kernel runs
+            // in its roomy form (2 wavefronts per SIMD, no spills in the wide copies).  A wrong guess only costs speed.
+            int around = 0;
+            const int here = (int)(e->step_index % kQlenRing);
+            for (int d = -kDrainLookBack; d <= kDrainLookAhead; d++) {
+                const int v = ((volatile int*)e->h_qlen)[(here + d + kQlenRing) % kQlenRing];
+                if (v > around) around = v;
+            }
+            drain = around <= kDrainMaxQueue;
+            roomy = around >= kRoomyMinQueue;
+        }
         const long long quads_per_wave = (((long long)e->P.N + 3) / 4 + 4LL * e->quad_grid - 1) / (4LL * e->quad_grid);
         if (quads_per_wave * 16 > kDrainListMax) drain = false;        // a workgroup's list must hold every env it steps
         if (e->drain_override >= 0) drain = e->drain_override != 0;
+        if (e->roomy_override >= 0) roomy = e->roomy_override != 0;
+        roomy = roomy && !drain;
     }
     // With timing on, the two kernels carry their own start / stop events (hipExtLaunchKernel: the
     // events read the dispatch packet's begin / end timestamps, i.e. the duration a kernel trace
@@ -362,7 +389,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, e->stream, e->P, io);
     };
     bool solver_ran = false;
-#define EVC_LAUNCH_(KDBG, KFAST, KDRAIN, KPLAIN, GRID, W)                                           \
+#define EVC_LAUNCH_(KDBG, KFAST, KDRAIN, KROOMY, KPLAIN, GRID, W)                                           \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \
             if (!dbg && !e->warmed && e->use_quad && e->compact) {                                 \
@@ -373,10 +400,12 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 pw.host_qlen = nullptr;                                                            \
                 hipLaunchKernelGGL(KDRAIN, dim3(GRID), dim3(256), 0, e->stream, pw, io);           \
                 hipLaunchKernelGGL(KFAST, dim3(GRID), dim3(256), 0, e->stream, pw, io);            \
+                hipLaunchKernelGGL(KROOMY, dim3(e->roomy_grid), dim3(256), 0, e->stream, pw, io);  \
                 e->warmed = true;                                                                  \
             }                                                                                      \
             if (dbg) launch(KDBG, GRID, 256, 0);                                                   \
             else if (drain) launch(KDRAIN, GRID, 256, 0);                                          \
+            else if (roomy) launch(KROOMY, e->roomy_grid, 256, 0);                                 \
             else launch(KFAST, GRID, 256, 0);                                                      \
             if (!drain) {                                                                          \
                 launch(solver_step_kernel<W>, e->solver_grid, 256, 1);                              \
@@ -388,14 +417,14 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         break;
 #define EVC_LAUNCH_QUAD(W)                                                                          \
     EVC_LAUNCH_((step_kernel_quad<true, W, true>), (step_kernel_quad<true, W, false>),             \
-                (step_kernel_quad<true, W, false>),                                                \
+                (step_kernel_quad<true, W, false>), (step_kernel_quad<true, W, false>),            \
                 (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, W)
 #define EVC_LAUNCH_CQUAD(W)                                                                         \
     EVC_LAUNCH_((step_kernel_cquad<true, W, true>), (step_kernel_cquad<true, W, false>),           \
-                (step_kernel_cquad<true, W, false, true>),                                         \
+                (step_kernel_cquad<true, W, false, true>), (step_kernel_cquad<true, W, false, false, 2>), \
                 (dbg ? step_kernel_cquad<false, W, true> : step_kernel_cquad<false, W, false>), e->quad_grid, W)
 #define EVC_LAUNCH_WAVE(W)                                                                          \
-    EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, W)
+    EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, W)
 #define EVC_LAUNCH_ALL(L)                                                                           \
     switch (words) {                                                                               \
         L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8)                                                    \
@@ -598,6 +627,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
         e->h_qlen = nullptr;
     }
     if (const char* s = getenv("EVC_DRAIN")) e->drain_override = atoi(s) != 0 ? 1 : 0;
+    if (const char* s = getenv("EVC_ROOMY")) e->roomy_override = atoi(s) != 0 ? 1 : 0;
     *out = e;
     return EVC_OK;
 }
