@@ -91,9 +91,10 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
 // slow kernel once a step queues more than a few dozen, evc_engine.hip "drain mode").
 //
 // WAVES: wavefronts per SIMD the register allocation is held to.  4 (128 VGPRs) is the streaming choice: the one-slot
-// copy of the iteration body fits, the wide copies (17 - 64 entries per environment) spill.  2 (172 VGPRs, no spill) is
+// copy of the iteration body fits, the wide copies (17 - 64 entries per environment) spill.  3 (168 VGPRs, no spill) is
 // the "roomy" form the engine launches on congested stretches of a day, where most wavefronts run a wide copy:
-// JPL's GMM day 45.2 -> 38.9 us per step for this kernel; on the quiet benchmark day it is 5 us slower (evc_engine.hip).
+// JPL's GMM day 45.2 -> 34.6 us per step for this kernel (38.3 at 2 per SIMD), Caltech's 43.4 -> 40.7; on the quiet
+// benchmark day it equals the streaming form with projection on and is 1.2 us slower without (evc_engine.hip).
 template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES>
 __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params P, StepIO io) {
     static_assert(!DRAIN || (PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");

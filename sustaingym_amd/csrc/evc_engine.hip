@@ -53,8 +53,11 @@ hipError_t dmalloc(T** p, size_t count) {
 
 constexpr bool kDefaultCompact = true;
 constexpr int kQlenRing = 288;           // one report per period of a day
+#ifndef EVC_ROOMY_WAVES
+#define EVC_ROOMY_WAVES 3               // wavefronts per SIMD of the lean compact kernel's roomy form (evc_cquad.h)
+#endif
 constexpr int kDrainLookBack = 12, kDrainLookAhead = 36;   // periods of the day around the current one whose reports decide the step's mode
-constexpr int kRoomyMinQueue = 64;      // queue length (around this time of day) from which the 2-waves-per-SIMD form of the lean kernel runs
+constexpr int kRoomyMinQueue = 64;      // queue length (around this time of day) from which the roomy (EVC_ROOMY_WAVES per SIMD) form of the lean kernel runs
 constexpr int kDrainMaxQueue = 16;      // in-kernel drain only while NO step of the last day queued more than this
 
 struct evc_engine {
@@ -282,9 +285,9 @@ void compute_grids(evc_engine* e) {
     if (qblocks >= 8) qblocks -= qblocks % 8;
     if (qblocks < 1) qblocks = 1;
     e->quad_grid = qblocks;
-    {   // the roomy form of the compact kernel: 2 workgroups per CU
+    {   // the roomy form of the compact kernel: EVC_ROOMY_WAVES workgroups per CU
         int rb = (((e->P.N + 3) / 4) + 3) / 4;
-        const int rcap = 2 * e->num_cus;
+        const int rcap = EVC_ROOMY_WAVES * e->num_cus;
         if (rb > rcap) rb = rcap;
         if (rb >= 8) rb -= rb % 8;
         e->roomy_grid = rb < 1 ? 1 : rb;
@@ -362,7 +365,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             // the last reports for this time of day — today's behind it (as far as the GPU has come), yesterday's ahead.
             // Quiet there (one hour back, three ahead): drain in the kernel — the nights of a congested day then cost one
             // launch per step instead of two.  Long queues there: most environments are crowded too, and the lean kernel runs
-            // in its roomy form (2 wavefronts per SIMD, no spills in the wide copies).  A wrong guess only costs speed.
+            // in its roomy form (3 wavefronts per SIMD, no spills in the wide copies).  A wrong guess only costs speed.
             int around = 0;
             const int here = (int)(e->step_index % kQlenRing);
             for (int d = -kDrainLookBack; d <= kDrainLookAhead; d++) {
@@ -421,7 +424,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, W)
 #define EVC_LAUNCH_CQUAD(W)                                                                         \
     EVC_LAUNCH_((step_kernel_cquad<true, W, true>), (step_kernel_cquad<true, W, false>),           \
-                (step_kernel_cquad<true, W, false, true>), (step_kernel_cquad<true, W, false, false, 2>), \
+                (step_kernel_cquad<true, W, false, true>), (step_kernel_cquad<true, W, false, false, EVC_ROOMY_WAVES>), \
                 (dbg ? step_kernel_cquad<false, W, true> : step_kernel_cquad<false, W, false>), e->quad_grid, W)
 #define EVC_LAUNCH_WAVE(W)                                                                          \
     EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, W)

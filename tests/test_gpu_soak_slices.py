@@ -22,7 +22,7 @@ def test_gmm_days_slice(site, drain, monkeypatch):
     from sustaingym_amd.synthetic import synthetic_moer
     # who solves what the streaming kernel queues: '1' = every workgroup drains its own list inside the
     # streaming kernel (no slow kernel at all), '0' = the slow kernel, 'auto' = the engine's day-long rule
-    # 'roomy' = the slow kernel behind the 2-wavefronts-per-SIMD form of the lean kernel (the engine's choice on congested stretches)
+    # 'roomy' = the slow kernel behind the roomy (3 wavefronts per SIMD, spill-free) form of the lean kernel (the engine's choice on congested stretches)
     if drain == 'roomy':
         monkeypatch.setenv('EVC_DRAIN', '0')
         monkeypatch.setenv('EVC_ROOMY', '1')
