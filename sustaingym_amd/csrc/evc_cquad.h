@@ -90,11 +90,12 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
 // kernel's; only several queued environments inside ONE workgroup serialise (the engine falls back to the
 // slow kernel once a step queues more than a few dozen, evc_engine.hip "drain mode").
 //
-// WAVES: wavefronts per SIMD the register allocation is held to.  4 (128 VGPRs) is the streaming choice: the one-slot
-// copy of the iteration body fits, the wide copies (17 - 64 entries per environment) spill.  3 (168 VGPRs, no spill) is
-// the "roomy" form the engine launches on congested stretches of a day, where most wavefronts run a wide copy:
-// JPL's GMM day 45.2 -> 34.6 us per step for this kernel (38.3 at 2 per SIMD), Caltech's 43.4 -> 40.7; on the quiet
-// benchmark day it equals the streaming form with projection on and is 1.2 us slower without (evc_engine.hip).
+// WAVES: wavefronts per SIMD the register allocation is held to.  At 4 (128 VGPRs) the one-slot copy of the iteration
+// body fits and the wide copies (17 - 64 entries per environment) spill; at 3 (168 VGPRs) a projecting kernel has no
+// spilled VGPR at all.  On the quiet benchmark day the two are equal with projection (26.3 us per step either way,
+// interleaved A/B) and 4 is 1.2 us faster without; on congested days, where most wavefronts run a wide copy, 3 wins:
+// Caltech's GMM day 42.1 -> 38.8 us per step, JPL's streaming kernel 45.2 -> 34.6 (38.3 at 2).  The engine launches the
+// projecting lean kernels at 3 (EVC_PROJ_WAVES, evc_engine.hip), everything else at EVC_CQUAD_WAVES.
 template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES>
 __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params P, StepIO io) {
     static_assert(!DRAIN || (PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");

@@ -53,11 +53,10 @@ hipError_t dmalloc(T** p, size_t count) {
 
 constexpr bool kDefaultCompact = true;
 constexpr int kQlenRing = 288;           // one report per period of a day
-#ifndef EVC_ROOMY_WAVES
-#define EVC_ROOMY_WAVES 3               // wavefronts per SIMD of the lean compact kernel's roomy form (evc_cquad.h)
+#ifndef EVC_PROJ_WAVES
+#define EVC_PROJ_WAVES 3                // wavefronts per SIMD the PROJECTING lean compact kernels are held to (evc_cquad.h, WAVES)
 #endif
 constexpr int kDrainLookBack = 12, kDrainLookAhead = 36;   // periods of the day around the current one whose reports decide the step's mode
-constexpr int kRoomyMinQueue = 64;      // queue length (around this time of day) from which the roomy (EVC_ROOMY_WAVES per SIMD) form of the lean kernel runs
 constexpr int kDrainMaxQueue = 16;      // in-kernel drain only while NO step of the last day queued more than this
 
 struct evc_engine {
@@ -116,8 +115,7 @@ struct evc_engine {
     unsigned long long env_steps = 0;
     int step_parity = 0;
     int num_cus = 256;
-    int step_grid = 0, solver_grid = 0, quad_grid = 0, roomy_grid = 0;
-    int roomy_override = -1;      // EVC_ROOMY=0/1 forces the choice (measurements, tests)
+    int step_grid = 0, solver_grid = 0, quad_grid = 0, proj_grid = 0;
     unsigned long long policy_seed = 0;   // EVC_ACTION_RANDOM (evc_set_policy_seed)
     unsigned env_id_base = 0;
     bool compact = false;        // state layout (Params::compact)
@@ -285,12 +283,13 @@ void compute_grids(evc_engine* e) {
     if (qblocks >= 8) qblocks -= qblocks % 8;
     if (qblocks < 1) qblocks = 1;
     e->quad_grid = qblocks;
-    {   // the roomy form of the compact kernel: EVC_ROOMY_WAVES workgroups per CU
+    {   // the projecting lean kernels of the compact layout: EVC_PROJ_WAVES workgroups per CU
         int rb = (((e->P.N + 3) / 4) + 3) / 4;
-        const int rcap = EVC_ROOMY_WAVES * e->num_cus;
+        int rcap = EVC_PROJ_WAVES * e->num_cus;
+        if (const char* s = getenv("EVC_GRID_CAP")) rcap = atoi(s) > 0 ? atoi(s) : rcap;
         if (rb > rcap) rb = rcap;
         if (rb >= 8) rb -= rb % 8;
-        e->roomy_grid = rb < 1 ? 1 : rb;
+        e->proj_grid = e->compact ? (rb < 1 ? 1 : rb) : e->quad_grid;
     }
     // the 4-environments-per-wavefront kernel evaluates constraint row c in lane c of a 16-lane
     // row and addresses whole arrays with 32-bit byte offsets
@@ -351,7 +350,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     const bool dbg = out->pilots || out->rates || out->projected || out->returns ||
                      action_kind == EVC_ACTION_GREEDY;
     // drain mode (see evc_engine): the lean compact streaming kernel can drain short queues itself
-    bool drain = false, roomy = false;
+    bool drain = false;
     if (e->P.project && e->use_quad && e->compact && !dbg && e->h_qlen) {
         // longest queue among the last day's reports; slots no kernel has written yet hold INT_MAX, so an engine
         // starts with the slow kernel and only drops it after a whole day of short queues (the host runs ahead of
@@ -364,8 +363,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             // A day with a congested part.  The ring is indexed by the period of the day, so the slots around this step's hold
             // the last reports for this time of day — today's behind it (as far as the GPU has come), yesterday's ahead.
             // Quiet there (one hour back, three ahead): drain in the kernel — the nights of a congested day then cost one
-            // launch per step instead of two.  Long queues there: most environments are crowded too, and the lean kernel runs
-            // in its roomy form (3 wavefronts per SIMD, no spills in the wide copies).  A wrong guess only costs speed.
+            // launch per step instead of two.  A wrong guess only costs speed.
             int around = 0;
             const int here = (int)(e->step_index % kQlenRing);
             for (int d = -kDrainLookBack; d <= kDrainLookAhead; d++) {
@@ -373,13 +371,10 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 if (v > around) around = v;
             }
             drain = around <= kDrainMaxQueue;
-            roomy = around >= kRoomyMinQueue;
         }
-        const long long quads_per_wave = (((long long)e->P.N + 3) / 4 + 4LL * e->quad_grid - 1) / (4LL * e->quad_grid);
+        const long long quads_per_wave = (((long long)e->P.N + 3) / 4 + 4LL * e->proj_grid - 1) / (4LL * e->proj_grid);
         if (quads_per_wave * 16 > kDrainListMax) drain = false;        // a workgroup's list must hold every env it steps
         if (e->drain_override >= 0) drain = e->drain_override != 0;
-        if (e->roomy_override >= 0) roomy = e->roomy_override != 0;
-        roomy = roomy && !drain;
     }
     // With timing on, the two kernels carry their own start / stop events (hipExtLaunchKernel: the
     // events read the dispatch packet's begin / end timestamps, i.e. the duration a kernel trace
@@ -392,7 +387,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, e->stream, e->P, io);
     };
     bool solver_ran = false;
-#define EVC_LAUNCH_(KDBG, KFAST, KDRAIN, KROOMY, KPLAIN, GRID, W)                                           \
+#define EVC_LAUNCH_(KDBG, KFAST, KDRAIN, KPLAIN, GRID, LEANGRID, W)                                        \
     case W:                                                                                        \
         if (e->P.project) {                                                                        \
             if (!dbg && !e->warmed && e->use_quad && e->compact) {                                 \
@@ -401,15 +396,13 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 Params pw = e->P;                                                                  \
                 pw.N = 0;                                                                          \
                 pw.host_qlen = nullptr;                                                            \
-                hipLaunchKernelGGL(KDRAIN, dim3(GRID), dim3(256), 0, e->stream, pw, io);           \
-                hipLaunchKernelGGL(KFAST, dim3(GRID), dim3(256), 0, e->stream, pw, io);            \
-                hipLaunchKernelGGL(KROOMY, dim3(e->roomy_grid), dim3(256), 0, e->stream, pw, io);  \
+                hipLaunchKernelGGL(KDRAIN, dim3(LEANGRID), dim3(256), 0, e->stream, pw, io);       \
+                hipLaunchKernelGGL(KFAST, dim3(LEANGRID), dim3(256), 0, e->stream, pw, io);        \
                 e->warmed = true;                                                                  \
             }                                                                                      \
             if (dbg) launch(KDBG, GRID, 256, 0);                                                   \
-            else if (drain) launch(KDRAIN, GRID, 256, 0);                                          \
-            else if (roomy) launch(KROOMY, e->roomy_grid, 256, 0);                                 \
-            else launch(KFAST, GRID, 256, 0);                                                      \
+            else if (drain) launch(KDRAIN, LEANGRID, 256, 0);                                      \
+            else launch(KFAST, LEANGRID, 256, 0);                                                  \
             if (!drain) {                                                                          \
                 launch(solver_step_kernel<W>, e->solver_grid, 256, 1);                              \
                 solver_ran = true;                                                                 \
@@ -420,14 +413,14 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         break;
 #define EVC_LAUNCH_QUAD(W)                                                                          \
     EVC_LAUNCH_((step_kernel_quad<true, W, true>), (step_kernel_quad<true, W, false>),             \
-                (step_kernel_quad<true, W, false>), (step_kernel_quad<true, W, false>),            \
-                (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, W)
+                (step_kernel_quad<true, W, false>),                                                \
+                (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, e->quad_grid, W)
 #define EVC_LAUNCH_CQUAD(W)                                                                         \
-    EVC_LAUNCH_((step_kernel_cquad<true, W, true>), (step_kernel_cquad<true, W, false>),           \
-                (step_kernel_cquad<true, W, false, true>), (step_kernel_cquad<true, W, false, false, EVC_ROOMY_WAVES>), \
-                (dbg ? step_kernel_cquad<false, W, true> : step_kernel_cquad<false, W, false>), e->quad_grid, W)
+    EVC_LAUNCH_((step_kernel_cquad<true, W, true>), (step_kernel_cquad<true, W, false, false, EVC_PROJ_WAVES>), \
+                (step_kernel_cquad<true, W, false, true, EVC_PROJ_WAVES>),                          \
+                (dbg ? step_kernel_cquad<false, W, true> : step_kernel_cquad<false, W, false>), e->quad_grid, e->proj_grid, W)
 #define EVC_LAUNCH_WAVE(W)                                                                          \
-    EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, W)
+    EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, e->step_grid, W)
 #define EVC_LAUNCH_ALL(L)                                                                           \
     switch (words) {                                                                               \
         L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8)                                                    \
@@ -630,7 +623,6 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
         e->h_qlen = nullptr;
     }
     if (const char* s = getenv("EVC_DRAIN")) e->drain_override = atoi(s) != 0 ? 1 : 0;
-    if (const char* s = getenv("EVC_ROOMY")) e->roomy_override = atoi(s) != 0 ? 1 : 0;
     *out = e;
     return EVC_OK;
 }

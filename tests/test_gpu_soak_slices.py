@@ -10,7 +10,7 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('drain', ['auto', '0', '1', 'roomy'])
+@pytest.mark.parametrize('drain', ['auto', '0', '1'])
 @pytest.mark.parametrize('site', ['caltech', 'jpl'])
 def test_gmm_days_slice(site, drain, monkeypatch):
     """2 048 device-generated GMM days (Summer 2019 model) per site, projection on, lean streaming kernel +
@@ -22,11 +22,7 @@ def test_gmm_days_slice(site, drain, monkeypatch):
     from sustaingym_amd.synthetic import synthetic_moer
     # who solves what the streaming kernel queues: '1' = every workgroup drains its own list inside the
     # streaming kernel (no slow kernel at all), '0' = the slow kernel, 'auto' = the engine's day-long rule
-    # 'roomy' = the slow kernel behind the roomy (3 wavefronts per SIMD, spill-free) form of the lean kernel (the engine's choice on congested stretches)
-    if drain == 'roomy':
-        monkeypatch.setenv('EVC_DRAIN', '0')
-        monkeypatch.setenv('EVC_ROOMY', '1')
-    elif drain != 'auto':
+    if drain != 'auto':
         monkeypatch.setenv('EVC_DRAIN', drain)
     net = site_str_to_site(site)
     n, N = net.num_stations, 2048
