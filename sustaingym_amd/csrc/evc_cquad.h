@@ -352,6 +352,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                 // if the point projected onto box and caps satisfies every row it is the projection
                 // (relaxation argument); what remains violated goes to the slow kernel.
                 bool fill = undecided && cap_viol != 0u;
+#ifdef EVC_ABL_NO_FILL              /* ablation builds only (wrong results): the exact rows without the water-filling */
+                if (fill) anyviol = false;
+                fill = false;
+#endif
                 if (__builtin_expect(__ballot(fill) != 0ull, 0)) {
                     bool slot_cc[kSlots];
 #pragma unroll
