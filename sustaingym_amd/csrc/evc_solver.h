@@ -431,13 +431,15 @@ __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, 
         bool conv = true;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const double nz = sqrt(z[2 * r] * z[2 * r] + z[2 * r + 1] * z[2 * r + 1]);
-            zh[2 * r] = z[2 * r] / nz;
-            zh[2 * r + 1] = z[2 * r + 1] / nz;
+            // one square root and one divide per row and iteration (the chain is latency: every IEEE divide is a dozen dependent instructions)
+            const double inz = 1.0 / sqrt(z[2 * r] * z[2 * r] + z[2 * r + 1] * z[2 * r + 1]);
+            zh[2 * r] = z[2 * r] * inz;
+            zh[2 * r + 1] = z[2 * r + 1] * inz;
             g[2 * r] = w[2 * r] - rmag[r] * zh[2 * r];
             g[2 * r + 1] = w[2 * r + 1] - rmag[r] * zh[2 * r + 1];
-            rn[r] = rmag[r] / nz;
-            conv = conv && sqrt(g[2 * r] * g[2 * r] + g[2 * r + 1] * g[2 * r + 1]) / rmag[r] <= Consts::PROJ_TOL_KKT;
+            rn[r] = rmag[r] * inz;
+            const double lim = Consts::PROJ_TOL_KKT * rmag[r];
+            conv = conv && g[2 * r] * g[2 * r] + g[2 * r + 1] * g[2 * r + 1] <= lim * lim;
         }
         if (conv) { yout = y; return true; }
         double B[D][D];
@@ -461,13 +463,14 @@ __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, 
         for (int a = 0; a < D; a++) B[a][a] += mu * scale;
         // Gauss elimination without pivoting (SPD + shift)
         bool good = true;
+        double inv[D];
 #pragma unroll
         for (int a = 0; a < D; a++) {
             good = good && B[a][a] > 0.0;
-            const double inv = 1.0 / B[a][a];
+            inv[a] = 1.0 / B[a][a];
 #pragma unroll
             for (int e = a + 1; e < D; e++) {
-                const double f = B[e][a] * inv;
+                const double f = B[e][a] * inv[a];
 #pragma unroll
                 for (int u = a + 1; u < D; u++) B[e][u] -= f * B[a][u];
                 g[e] -= f * g[a];
@@ -479,7 +482,7 @@ __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, 
             double t = g[a];
 #pragma unroll
             for (int u = a + 1; u < D; u++) t -= B[a][u] * d[u];
-            d[a] = t / B[a][a];
+            d[a] = t * inv[a];
         }
         if (!good) return false;
 #pragma unroll
