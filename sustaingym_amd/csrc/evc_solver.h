@@ -371,16 +371,23 @@ __device__ __forceinline__ ExactRows exact_rows_worst(const Params& P, const Lds
             }
         }
     }
+    // squared ratios order the rows like the ratios do: no square root, one divide
     double ratio = 0.0;
-    if (lane < P.m) ratio = sqrt(re * re + im * im) / net.mag[lane];
-    const bool viol = lane < P.m && ratio > 1.0 + Consts::PROJ_TOL;
+    bool viol = false;
+    if (lane < P.m) {
+        const double mg = net.mag[lane], lim = mg * (1.0 + Consts::PROJ_TOL), m2 = re * re + im * im;
+        viol = m2 > lim * lim;
+        ratio = m2 / (mg * mg);
+    }
     out.viol = __ballot(viol);
     if (out.viol != 0ull) {
-        // rows live in lanes 0..31: maximum over those by a butterfly, then the first lane that holds it
+        // rows live in lanes 0..31: maximum inside the two 16-lane DPP rows, then across them; the first lane that holds it
         double best = viol ? ratio : 0.0;
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) best = fmax(best, __shfl_xor(best, off));
-        best = readlane_f64(best, 0);
+        best = fmax(best, dpp_f64<0x121, 0xf, false>(best));
+        best = fmax(best, dpp_f64<0x122, 0xf, false>(best));
+        best = fmax(best, dpp_f64<0x124, 0xf, false>(best));
+        best = fmax(best, dpp_f64<0x128, 0xf, false>(best));
+        best = fmax(readlane_f64(best, 0), readlane_f64(best, 16));
         out.worst = __builtin_ctzll(__ballot(viol && ratio == best) | (1ull << 63));
     }
     return out;
