@@ -86,6 +86,8 @@ def lib() -> C.CDLL:
         L.orc_batch_reset.argtypes = [vp, vp, vp]
         L.orc_batch_step.argtypes = [vp, vp, vp, i32, i32, i32, i32] + [vp] * 9
         L.orc_max_threads.restype = i32
+        L.orc_batch_station_state.argtypes = [vp, vp, vp, vp]
+        L.orc_batch_rollout.argtypes = [vp, i32, i32, C.c_uint64, C.c_uint32, vp, i32, i32, i32, i32] + [vp] * 7
         L.orc_philox4x32.argtypes = [C.c_uint32] * 6 + [vp]
         L.orc_gen_log.restype = C.c_double
         L.orc_gen_log.argtypes = [C.c_double]
@@ -265,6 +267,38 @@ class OracleBatch:
                              _p(out['breakdown']), _p(out['final_obs']), _p(out.get('pilots')),
                              _p(out.get('rates')), _p(out.get('projected')), _p(out['status']))
         return out
+
+
+def _batch_station_state(self):
+    rem = np.zeros((self.N, self.n), np.float64)
+    dep = np.zeros((self.N, self.n), np.int16)
+    est = np.zeros((self.N, self.n), np.int16)
+    lib().orc_batch_station_state(self.handle, _p(rem), _p(dep), _p(est))
+    return rem, dep, est
+
+
+def _batch_rollout(self, policy: str, obs: np.ndarray, steps: int = 288, bins: int = 0, seed: int = 0,
+                   env_id_base: int = 0, episodes=None, autoreset: bool = False, threads: int = 0):
+    """BaseAlgorithm.run's loop (algorithms/base.py:63-88) under 'greedy' / 'random' for every environment;
+    ``obs`` = the current observations [N, F].  Returns the outputs of the last step + 'returns' + 'episodes'."""
+    N, F = self.N, self.F
+    out = {
+        'obs': np.ascontiguousarray(obs, dtype=np.float32).copy(), 'reward': np.zeros(N, np.float64),
+        'terminated': np.zeros(N, np.uint8), 'breakdown': np.zeros((N, 3), np.float64),
+        'final_obs': np.zeros((N, F), np.float32), 'returns': np.zeros(N, np.float64),
+        'status': np.zeros(N, np.uint32),
+        'episodes': np.zeros(N, np.int32) if episodes is None else np.ascontiguousarray(episodes, dtype=np.int32).copy(),
+    }
+    lib().orc_batch_rollout(self.handle, {'greedy': 2, 'random': 3}[policy], int(bins), int(seed) & (2 ** 64 - 1),
+                            int(env_id_base), _p(out['episodes']), int(steps), int(autoreset), self.stride,
+                            threads if threads > 0 else default_threads(), _p(out['obs']), _p(out['reward']),
+                            _p(out['terminated']), _p(out['breakdown']), _p(out['final_obs']), _p(out['returns']),
+                            _p(out['status']))
+    return out
+
+
+OracleBatch.station_state = _batch_station_state
+OracleBatch.rollout = _batch_rollout
 
 
 def random_actions(seed: int, env_ids, episodes, t, n: int, bins: int = 0) -> np.ndarray:

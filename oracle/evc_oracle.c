@@ -619,3 +619,71 @@ void orc_batch_step(orc_batch* b, const float* actions, const int64_t* discrete,
         }
     }
 }
+
+void orc_batch_station_state(const orc_batch* b, double* remaining, int16_t* departure,
+                             int16_t* est_departure) {
+    const int n = b->net->n;
+    for (int i = 0; i < b->N; i++)
+        orc_env_station_state(b->envs[i], remaining + (size_t)i * n, departure + (size_t)i * n,
+                              est_departure + (size_t)i * n);
+}
+
+/* The episode loop of BaseAlgorithm.run (sustaingym/algorithms/base.py:63-88) for the two arithmetic-free
+ * baselines, every environment of the batch on its own (OpenMP over environments):
+ *   policy 2 = GreedyAlgorithm.get_action (algorithms/evcharging/baselines.py:32-35): 1 where the observed
+ *              demand is non-zero, else 0;
+ *   policy 3 = RandomAlgorithm.get_action (baselines.py:45-51) on the counter-based stream of
+ *              orc_random_action (seed, env_id_base + i, episodes done, period t).
+ * obs [N][F]: in = the current observations (what reset / the previous step returned), out = those after the
+ * last step.  returns[i] += every reward.  Without autoreset a finished environment stops stepping (reward 0,
+ * terminated 1), like the reference's `while not done`. */
+void orc_batch_rollout(orc_batch* b, int policy, int bins, uint64_t seed, uint32_t env_id_base,
+                       int32_t* episodes /* [N] in/out */, int steps, int autoreset, int autoreset_stride,
+                       int threads, float* obs, double* reward, uint8_t* terminated, double* breakdown,
+                       float* final_obs, double* returns, uint32_t* status) {
+    const int n = b->net->n;
+    const int F = 2 * n + b->k + 2;
+#ifdef _OPENMP
+    int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 16)
+#else
+    (void)threads;
+#endif
+    for (int i = 0; i < b->N; i++) {
+        orc_env* e = b->envs[i];
+        float* row = obs + (size_t)i * F;
+        float act[ORC_MAX_STATIONS];
+        int64_t level[ORC_MAX_STATIONS];
+        orc_step_result res;
+        uint32_t st = 0;
+        for (int s = 0; s < steps; s++) {
+            if (e->done) {                       /* step after termination: ignored */
+                reward[i] = 0.0;
+                terminated[i] = 1;
+                break;
+            }
+            if (policy == 2) {
+                for (int j = 0; j < n; j++) act[j] = row[j] > 0.0f ? 1.0f : 0.0f;
+            } else {
+                orc_random_action(seed, env_id_base + (uint32_t)i, (uint32_t)episodes[i], (uint32_t)e->t, n, bins, act);
+            }
+            (void)level;
+            orc_env_step(e, act, row, &res);
+            st |= res.status;
+            reward[i] = res.reward;
+            terminated[i] = (uint8_t)res.terminated;
+            if (returns) returns[i] += res.reward;
+            if (breakdown) memcpy(breakdown + (size_t)i * 3, res.breakdown, sizeof(double) * 3);
+            if (res.terminated) {
+                episodes[i] += 1;
+                if (autoreset) {
+                    if (final_obs) memcpy(final_obs + (size_t)i * F, row, sizeof(float) * F);
+                    int next = (int)(((long)b->slot[i] + autoreset_stride) % b->bank_slots);
+                    batch_reset_one(b, i, next, row);
+                }
+            }
+        }
+        if (status) status[i] = st;
+    }
+}
+

@@ -20,6 +20,7 @@
 #include "evc_solver.h"
 #include "evc_quad.h"
 #include "evc_cquad.h"
+#include "evc_rollout_launch.h"
 #include "evc_gen.h"
 
 using namespace evc;
@@ -448,6 +449,41 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     return EVC_OK;
 }
 
+// The fused rollout (evc_rollout.h): `steps` periods of a device-resident policy in ONE launch.  Available for the
+// compact layout's quad geometry, when no per-station debug output is requested.
+bool fused_rollout_available(const evc_engine* e, int action_kind, const evc_step_out* out) {
+    if (action_kind != EVC_ACTION_GREEDY && action_kind != EVC_ACTION_RANDOM) return false;
+    if (!e->use_quad || !e->compact) return false;
+    if (out->pilots || out->rates || out->projected) return false;
+    if (const char* s = getenv("EVC_ROLLOUT_FUSED")) return atoi(s) != 0;      // measurements / tests: 0 = the loop of steps
+    return true;
+}
+
+int launch_rollout(evc_engine* e, int action_kind, int bins, int steps, const evc_step_out* out) {
+    if (!out || !out->obs || !out->reward || !out->terminated)
+        return fail(EVC_EINVAL, "evc_rollout: out->obs, out->reward, out->terminated required");
+    if (action_kind == EVC_ACTION_RANDOM && bins == 1)
+        return fail(EVC_EINVAL, "evc_rollout: random discrete actions need bins >= 2 (bins <= 0: continuous)");
+    RolloutIO io;
+    io.policy = action_kind;
+    io.bins = bins;
+    io.steps = steps;
+    io.env_id_base = e->env_id_base;
+    io.seed = e->policy_seed;
+    io.out = *out;
+    const int grid = (((e->P.N + 3) / 4) + 3) / 4;          // one quad of environments per wavefront
+    if (!launch_rollout_kernel(e->P, io, grid, e->stream, e->timing ? e->ev[0] : nullptr, e->timing ? e->ev[1] : nullptr))
+        return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
+    if (e->timing) {
+        e->ev_valid = true;
+        e->ev_slow = false;
+    }
+    HIP_TRY(hipGetLastError());
+    e->env_steps += (unsigned long long)e->P.N * (unsigned long long)steps;
+    e->step_index += (unsigned long long)steps;
+    return EVC_OK;
+}
+
 int ensure_staging(evc_engine* e) {
     if (e->d_obs) return EVC_OK;
     const size_t N = e->P.N, n = e->P.n, F = e->P.F;
@@ -859,6 +895,7 @@ int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int
     if (!device_policy && (!actions_dev || ring_len < 1))
         return fail(EVC_EINVAL, "evc_rollout: actions and ring_len >= 1 required");
     if (int rc = bind(e)) return rc;
+    if (out && fused_rollout_available(e, action_kind, out)) return launch_rollout(e, action_kind, bins, steps, out);
     const size_t elem = action_kind == EVC_ACTION_DISCRETE ? 8 : 4;
     const size_t stride = (size_t)e->P.N * e->P.n * elem;
     for (int i = 0; i < steps; i++) {

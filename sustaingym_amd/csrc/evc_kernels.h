@@ -526,6 +526,9 @@ __global__ __launch_bounds__(256) void step_kernel(Params P, StepIO io) {
     }
 }
 
+constexpr unsigned kPolicyTag = 0x504f4c43u;      // random policy: last counter word (see random_actions_kernel)
+
+#ifndef EVC_TEMPLATES_ONLY      /* the non-template kernels belong to ONE translation unit (evc_engine.hip) */
 // ------------------------------------------------------------------------------------------
 // reset kernel (env.py:293-338): one wave per listed environment.
 // ------------------------------------------------------------------------------------------
@@ -562,7 +565,6 @@ __global__ __launch_bounds__(256) void discretize_kernel(const long long* in, fl
 //   word j -> station 4 block + j;  continuous: a = (w >> 8) 2^-24 in [0,1);  discrete (bins >= 2):
 //   level = (w bins) >> 32, a = float(level) / float(bins - 1)  (wrappers.py:43-45).
 // (include/evcharge.h: evc_set_policy_seed states the rule; the tests hold an independent scalar C statement of it.)
-constexpr unsigned kPolicyTag = 0x504f4c43u;
 __global__ __launch_bounds__(256) void random_actions_kernel(const int4* __restrict__ scal, float* __restrict__ out,
                                                              int N, int n, int bins, unsigned long long seed,
                                                              unsigned env_id_base) {
@@ -658,5 +660,7 @@ __global__ __launch_bounds__(256) void metrics_kernel(Params P, double* out) {
         out[7] = near;
     }
 }
+
+#endif  // EVC_TEMPLATES_ONLY
 
 }  // namespace evc

@@ -1,0 +1,545 @@
+// evc_rollout.h — the fused multi-period rollout: T consecutive EVChargingEnv.step() calls under a
+// device-resident policy in ONE launch (the reference's episode loop is
+// BaseAlgorithm.run, algorithms/base.py:63-88, over GreedyAlgorithm / RandomAlgorithm,
+// algorithms/evcharging/baselines.py:22-51).
+//
+// Geometry of evc_cquad.h — a wavefront = four 16-lane DPP rows = four environments, lane q of a row
+// owns entry slots q, q+16, q+32, q+48 of its environment — but the wavefront KEEPS its quad for all T
+// periods: the plugged-in EVs (entry word + remaining demand), the event cursor, the reward accumulators
+// and the episode return live in registers from the first period to the last.  Per period there is
+//   * no action read: GreedyAlgorithm's action is `remaining demand > 0` of the entry itself;
+//     RandomAlgorithm's is Philox4x32-10 of (seed, env, episode, period, station), drawn by lane q of the
+//     row for stations 4q..4q+3 — the stream of random_actions_kernel / evc_fill_random_actions, bit for bit;
+//   * no observation write, no state write-back: the observation a policy of this kind needs IS the state;
+//   * one row-uniform load (the MOER value of the period) and the session records that arrive;
+//   * no launch boundary: wavefronts are never synchronised with each other, so a wavefront that meets a
+//     congested period (exact rows, water-filling, an iterative solve) only delays its own four
+//     environments — there is no per-period tail for the whole batch to wait for.
+// An environment whose projection needs the iterative solver (cone rows binding) is solved where it stands:
+// its row hands targets and caps to a station-shaped LDS image, the wavefront runs the slow path's
+// solve_projection (evc_solver.h) behind one real call — same relaxation sequence, same tie snap as the
+// slow kernel — and the entries read their projected values back.
+// After the last period the state goes back to memory in the compact layout and the outputs of the LAST
+// step (observation, reward, terminated, breakdown; returns += every reward) are written once: the launch is
+// equivalent to T calls of evc_step (terminal observations of episodes that end inside the rollout included).
+#pragma once
+
+#include "evc_cquad.h"
+#include "evc_rollout_launch.h"
+
+namespace evc {
+
+constexpr unsigned kEmptyMeta = 0xffffffffu;      // entry word of a free slot (departure 1023: never reached)
+
+struct RolloutLds {
+    LdsNet net;
+    SolverWs ws[4];                                // one solver workspace per wavefront
+    float act_img[4][4][64];                       // [wave][row][station] action of this period (random policy)
+    // [wave][row][station], zero at rest, two users: (a) float2 {demand, est_departure} while an observation row is
+    // written; (b) the hand-off of the iterative projection: the row's entries put their caps h there, the solve leaves
+    // the projected values y in the same cells
+    union Cell {
+        float2 obs;
+        double h_or_y;
+    } img[4][4][64];
+    uint4 st_mulw[64];
+    uint4 st_mulw_hi[64];
+    unsigned char st_info[64];
+    int noconv[4];                                 // per wavefront: bit r = the solve of row r did not converge
+};
+
+constexpr unsigned kRolloutKernargBytes = (unsigned)((((sizeof(Params) + alignof(RolloutIO) - 1) / alignof(RolloutIO)) * alignof(RolloutIO) + sizeof(RolloutIO) + 7u) & ~(size_t)7u);
+
+// The iterative projection of the rows in `rows` (bit r = row r of wavefront wv; bit 4 = random policy): lane i =
+// station i of the row's environment.  Caps h come from S.img[wv][r] (0 where no EV is plugged in), targets are
+// b = 32 a with a = the action image (random policy) or 1 (greedy: a = 1 wherever the cap is non-zero, and where the
+// cap is zero the target does not matter); the projected values go back into the same cells.
+// Behind a real call for the reason given at drain_local_list (evc_cquad.h): inlined, the solver's live ranges
+// would sit in the period loop.  Params come from the kernel-argument segment.
+__device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsigned wv, unsigned rows) {
+    const char* ka = (const char*)__builtin_amdgcn_implicitarg_ptr() - kRolloutKernargBytes;
+    const Params& P = *(const Params*)ka;
+    typedef __attribute__((address_space(3))) RolloutLds LdsImage;
+    RolloutLds& S = *(RolloutLds*)(LdsImage*)(size_t)(unsigned)rfl((int)lds);
+    const int w = rfl((int)wv);
+    const unsigned mask = (unsigned)rfl((int)rows);
+    const int lane = (int)__lane_id();
+    SolverLds L(S.net, S.ws[w]);
+    const LaneNet lnet = lane_net(P, lane);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+        if (!((mask >> r) & 1u)) continue;
+        SolverLane ln;
+        ln.gid = lnet.gid;
+        ln.h = S.img[w][r][lane].h_or_y;
+        ln.b = (mask & 16u) ? (double)S.act_img[w][r][lane] * Consts::ACTION_SCALE_FACTOR : Consts::ACTION_SCALE_FACTOR;
+        ln.y = 0.0;
+        bool noconv;
+        const double y = solve_projection(P, L, lnet, ln, lane, noconv);
+        S.img[w][r][lane].h_or_y = y;
+        if (noconv && lane == 0) S.noconv[w] |= 1 << r;
+        SOLVER_SYNC();
+    }
+}
+
+#ifndef EVC_ROLLOUT_WAVES
+#define EVC_ROLLOUT_WAVES 3
+#endif
+
+template <bool PROJECT, int WORDS, bool RANDOM>
+__global__ __launch_bounds__(256, EVC_ROLLOUT_WAVES) void rollout_kernel(Params P, RolloutIO io) {
+    __shared__ RolloutLds S;
+    LdsNet& net = S.net;
+    auto& st_mulw = S.st_mulw;
+    auto& st_mulw_hi = S.st_mulw_hi;
+    auto& st_info = S.st_info;
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u, q = lane & 15u, row = lane >> 4;
+    const unsigned wv = (unsigned)rfl((int)(tid >> 6));
+    const unsigned n = (unsigned)P.n, F = (unsigned)P.F;
+    const unsigned m = (unsigned)P.m, k = (unsigned)P.k;
+    const unsigned N = (unsigned)P.N;
+
+    // ---- workgroup prologue: network tables, per-station multipliers, clean images ----
+    if (tid < 64u) {
+        const unsigned s = tid;
+        const bool valid = s < n;
+        int gid = 0;
+        for (int g = 0; g < P.G; g++)
+            if ((P.group_mask[g] >> s) & 1ull) gid = g;
+        unsigned mw[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) mw[w] = (valid && (gid >> 1) == w) ? ((gid & 1) ? 65536u : 1u) : 0u;
+        st_mulw[s] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+        st_mulw_hi[s] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
+        st_info[s] = (unsigned char)((unsigned)gid | ((unsigned)((P.cc_mask >> s) & 1ull) << 7));
+    }
+    if (tid < 4u) S.noconv[tid] = 0;
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) S.img[wv][row][j * 16 + q].h_or_y = 0.0;
+    stage_net(net, P);                              // ends with the workgroup barrier
+
+    const unsigned nquads = (N + 3u) >> 2;
+    const unsigned quad = blockIdx.x * 4u + wv;
+    if (quad >= nquads) return;                     // (after the only barrier)
+    const unsigned env = quad * 4u + row;
+    const bool ev = env < N;
+    const unsigned ebase = env * n;
+
+    const rsrc_t r_win = row_rsrc(P.win_base, P.win_span);
+    const Win r_rem{r_win, P.off_rem}, r_de{r_win, P.off_de}, r_scal{r_win, P.off_scal}, r_acc{r_win, P.off_acc};
+    const Win r_sess{r_win, P.off_sess}, r_req{r_win, P.off_req}, r_hist{r_win, P.off_hist};
+
+    float* const act_row = S.act_img[wv][row];
+    RolloutLds::Cell* const img_row = S.img[wv][row];
+    auto lds_sync = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto station_mulw = [&](unsigned st, unsigned (&mw)[WORDS]) {
+        const uint4 lo = st_mulw[st];
+        const unsigned all[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+        for (int w = 0; w < WORDS && w < 4; w++) mw[w] = all[w];
+        if (WORDS > 4) {
+            const uint4 hi = st_mulw_hi[st];
+            const unsigned allh[4] = {hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int w = 4; w < WORDS; w++) mw[w] = allh[w - 4];
+        }
+    };
+
+    // ---- the quad's state: memory -> registers ----
+    int t, cursor, slot, moer_day, n_sessions, next_arrival, status, episodes;
+    unsigned meta[kSlots];
+    double rem[kSlots];
+    {
+        const unsigned soff = ev ? env * 32u : kOob;
+        const v4u s0 = buf_ld_v4(r_scal, soff);
+        const v4u s1 = buf_ld_v4(r_scal, soff == kOob ? kOob : soff + 16u);
+        t = (int)s0.x; cursor = (int)s0.y; slot = (int)s0.z; moer_day = (int)s0.w;
+        n_sessions = (int)s1.x; next_arrival = (int)s1.y; status = (int)s1.z & kStatusMask; episodes = (int)s1.w;
+        const unsigned A = ev ? ((s1.z >> kCountShift) & 0x7fu) : 0u;
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) {
+            const unsigned e = (unsigned)c * 16u + q;
+            const unsigned w = buf_ld_u32(r_de, e < A ? (ebase + e) * 4u : kOob);
+            const double r = buf_ld_f64(r_rem, e < A ? (ebase + e) * 8u : kOob);
+            meta[c] = e < A ? w : kEmptyMeta;
+            rem[c] = e < A ? r : 0.0;
+        }
+        if (!ev) { t = EVC_EPISODE_STEPS; next_arrival = kNoArrival; n_sessions = 0; cursor = 0; }
+    }
+    double acc = buf_ld_f64(r_acc, (ev && q < 3u) ? env * 24u + q * 8u : kOob);   // lane q < 3: accumulator q
+    double bd = acc;                                 // breakdown as of the last live step
+    double ret = (io.out.returns && ev) ? io.out.returns[env] : 0.0;
+    double reward = 0.0;
+    bool done_last = false, ever_live = false;
+
+    const bool stepwise = P.battery_stepwise != 0;
+    const unsigned blocks_per_env = (n + 3u) >> 2;
+
+    // observation of the row's CURRENT state (env.py:381-394) into `dst` (obs / final_obs) for rows with `on`
+    auto emit_obs = [&](float* dst_base, bool on) {
+        const rsrc_t r_dst = row_rsrc(dst_base, N * F * 4u);
+        const unsigned obase = env * F;
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) {
+            if (on && meta[c] != kEmptyMeta) {
+                const bool active = rem[c] > Consts::FULLY_CHARGED_EPS;
+                img_row[entry_station(meta[c])].obs = make_float2(active ? (float)rem[c] : 0.0f,
+                                                                  active ? (float)(entry_est(meta[c]) - t) : 0.0f);
+            }
+        }
+        lds_sync();
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const float2 d = img_row[j * 16 + q].obs;
+            img_row[j * 16 + q].h_or_y = 0.0;
+            const bool w = on && (unsigned)j * 16u + q < n;
+            const unsigned o = (obase + (unsigned)j * 16u + q) * 4u;
+            buf_st_f32(r_dst, w ? o : kOob, d.x);
+            buf_st_f32(r_dst, w ? o + n * 4u : kOob, d.y);
+        }
+        const unsigned mrow = (unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const unsigned idx = (unsigned)p * 16u + q;                 // position in [forecast | prev | ts]
+            const unsigned col = idx < k ? idx + 1u : 0u;
+            const unsigned o_moer = P.off_moer + (mrow * EVC_MOER_COLS + col) * 4u;
+            const unsigned o_ts = P.off_ts + (unsigned)t * 4u;
+            const float v = buf_ld_f32(r_win, (on && idx <= k + 1u) ? (idx <= k ? o_moer : o_ts) : kOob);
+            buf_st_f32(r_dst, (on && idx < k + 2u) ? (obase + 2u * n + idx) * 4u : kOob, v);
+        }
+        lds_sync();
+    };
+
+    for (int step = 0; step < io.steps; step++) {
+        const bool after_done = ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
+        const bool live = ev && !after_done;
+        if (after_done) { status |= EVC_STATUS_STEP_AFTER_DONE; reward = 0.0; done_last = true; }
+        if (__ballot(live) == 0ull) break;                        // every later step of this quad is the same no-op
+        ever_live = ever_live || live;
+        const int t1 = t + 1;
+        // loads of the period, issued first: the MOER value of the reward, the session record at the cursor
+        const double moer_now = buf_ld_f64(r_hist, live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) * 8u : kOob);
+        bool pending = live && next_arrival <= t1 && cursor < n_sessions;
+        unsigned sidx = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
+        v2u sv = buf_ld_v2(r_sess, pending ? sidx * 8u : kOob);
+        double rq = buf_ld_f64(r_req, pending ? sidx * 8u : kOob);
+
+        // action image of the random policy: lane q draws stations 4q..4q+3 of its row
+        if (RANDOM) {
+            float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (live && q < blocks_per_env) {
+                const Philox ph((unsigned)t | (q << 16), (unsigned)episodes, io.env_id_base + env, kPolicyTag,
+                                (unsigned)io.seed, (unsigned)(io.seed >> 32));
+                float a[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned w = ph.w[j];
+                    if (io.bins >= 2) a[j] = (float)(unsigned)(((unsigned long long)w * (unsigned)io.bins) >> 32) / (float)(io.bins - 1);
+                    else a[j] = (float)(w >> 8) * (1.0f / 16777216.0f);
+                }
+                a4 = make_float4(a[0], a[1], a[2], a[3]);
+            }
+            *reinterpret_cast<float4*>(&act_row[4u * q]) = a4;
+            lds_sync();
+        }
+        const bool station_pilots = !PROJECT && RANDOM;          // see evc_cquad.h
+        double total_rate = 0.0, excess = 0.0;                   // what the period's body hands to the reward
+
+        auto body = [&](auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+        // ---- entries: decode, action, y (box clip of the projection), class sums ----
+        bool valid[kSlots];
+        unsigned st[kSlots];
+        int dep[kSlots];
+        float act[kSlots];
+        double y[kSlots];
+        unsigned ywords[WORDS], pwords[WORDS];
+#pragma unroll
+        for (int w = 0; w < WORDS; w++) { ywords[w] = 0u; pwords[w] = 0u; }
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) { valid[c] = false; st[c] = 0u; dep[c] = kEmptyDep; act[c] = 0.0f; y[c] = 0.0; }
+#pragma unroll
+        for (int c = 0; c < NS; c++) {
+            valid[c] = live && meta[c] != kEmptyMeta;
+            st[c] = (unsigned)entry_station(meta[c]);
+            dep[c] = valid[c] ? entry_dep(meta[c]) : kEmptyDep;
+            float a = RANDOM ? act_row[st[c]] : ((rem[c] > Consts::FULLY_CHARGED_EPS) ? 1.0f : 0.0f);   // baselines.py:32-35 / :45-51
+            a = valid[c] ? a : 0.0f;
+            act[c] = a;
+            double yy = (double)a * Consts::ACTION_SCALE_FACTOR;        // env.py:366
+            if (PROJECT) {
+                yy = fmin(yy, quad_demand_cap(dep[c], rem[c]));
+                const unsigned qy = (unsigned)(int)ceil(yy * 8.0);
+                unsigned mw[WORDS];
+                station_mulw(st[c], mw);
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) ywords[w] = __umul24(qy, mw[w]) + ywords[w];
+            }
+            y[c] = yy;
+        }
+
+        // ---- projection (env.py:178-221): screen -> exact rows -> in-row water-filling -> iterative solve ----
+        bool pilots_screened = false;
+        if (PROJECT) {
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) ywords[w] = row_allreduce_u32(ywords[w]);
+            bool maybe = false, maybe_p = false;
+            if (q < m) {
+                const float mag2 = quad_mag2_f32<WORDS>(net, q, ywords);
+                maybe = !(mag2 < net.thr_y2[q]);
+                maybe_p = !(mag2 < net.thr_yp2[q]);
+            }
+            const bool undecided = live && row_any(maybe, row);
+            pilots_screened = !row_any(maybe_p, row);
+            if (__builtin_expect(__ballot(undecided) != 0ull, 0)) {
+                int st_gid[kSlots];
+#pragma unroll
+                for (int c = 0; c < kSlots; c++) st_gid[c] = valid[c] ? (int)(st_info[st[c]] & 0x7fu) : -1;
+                unsigned cap_viol;
+                const bool hard = quad_exact_rows(P, net, q, m, st_gid, y, undecided, cap_viol);
+                bool anyviol = row_any(hard, row);
+                const bool fill = undecided && cap_viol != 0u;
+                if (__builtin_expect(__ballot(fill) != 0ull, 0)) {
+                    bool slot_cc[kSlots];
+#pragma unroll
+                    for (int c = 0; c < kSlots; c++) slot_cc[c] = valid[c] && (st_info[st[c]] >> 7) != 0u;
+                    for (int g = 0; g < P.G; g++) {
+                        const bool do_g = fill && ((cap_viol >> g) & 1u);
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, nullptr);
+                    }
+                    unsigned cv2;
+                    const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, P.snap_tol), row);
+                    anyviol = anyviol && !(fill && !still);
+                }
+                const bool solve_me = undecided && anyviol;       // cone rows bind (or unsettled): iterative solver
+                const unsigned long long solve_mask = __ballot(solve_me);
+                if (__builtin_expect(solve_mask != 0ull, 0)) {
+                    // the rows' caps, station-shaped (free stations stay 0)
+#pragma unroll
+                    for (int c = 0; c < NS; c++)
+                        if (solve_me && valid[c]) img_row[st[c]].h_or_y = quad_demand_cap(dep[c], rem[c]);
+                    const unsigned rows = ((solve_mask & 0xffffull) ? 1u : 0u) | ((solve_mask & 0xffff0000ull) ? 2u : 0u) |
+                                          ((solve_mask & 0xffff00000000ull) ? 4u : 0u) | ((solve_mask >> 48) ? 8u : 0u) |
+                                          (RANDOM ? 16u : 0u);
+                    lds_sync();
+                    rollout_solve_rows((unsigned)(size_t)(__attribute__((address_space(3))) void*)&S, wv, rows);
+                    lds_sync();
+#pragma unroll
+                    for (int c = 0; c < NS; c++)
+                        if (solve_me && valid[c]) {
+                            y[c] = img_row[st[c]].h_or_y;
+                            img_row[st[c]].h_or_y = 0.0;
+                        }
+                    if (solve_me && ((S.noconv[wv] >> row) & 1)) status |= EVC_STATUS_PROJ_NOCONV;
+                    lds_sync();
+                    if (lane == 0u) S.noconv[wv] = 0;
+                    lds_sync();
+                }
+                pilots_screened = pilots_screened && !undecided;
+            }
+        }
+
+#ifdef EVC_ROLLOUT_TRACE          /* debug builds only: -DEVC_ROLLOUT_TRACE=<env> -DEVC_ROLLOUT_TRACE_T=<t> */
+        if (ev && env == (unsigned)(EVC_ROLLOUT_TRACE) && t == (EVC_ROLLOUT_TRACE_T)) {
+#pragma unroll
+            for (int c = 0; c < NS; c++)
+                if (valid[c]) printf("trace NS=%d lane %u slot %d st %u dep %d rem %.9f act %.3f y %.9f screened %d\n", NS, lane, c, st[c], dep[c], rem[c], (double)act[c], y[c], (int)pilots_screened);
+        }
+#endif
+        // ---- pilots (env.py:366-378), battery charge ----
+        double pilot[kSlots], amps[kSlots], rem_in[kSlots];
+        bool cross[kSlots];
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) { pilot[c] = 0.0; amps[c] = 0.0; rem_in[c] = 0.0; cross[c] = false; }
+#pragma unroll
+        for (int c = 0; c < NS; c++) {
+            const unsigned info = st_info[st[c]];
+            const double pl = legal_pilot(y[c], (info >> 7) != 0u);     // y = 0 on free slots
+            pilot[c] = pl;
+            rem_in[c] = rem[c];
+            amps[c] = charge_ev_main(pl, rem[c], stepwise, cross[c]);    // a free slot (or a row that is not live) has pilot 0: nothing moves
+        }
+        {
+            bool any_cross = false;
+#pragma unroll
+            for (int c = 0; c < NS; c++) any_cross = any_cross || cross[c];
+            if (__builtin_expect(__ballot(any_cross) != 0ull, 0)) {
+#pragma unroll
+                for (int c = 0; c < NS; c++)
+                    if (cross[c]) amps[c] = charge_ev_cross(pilot[c], rem_in[c], rem[c]);
+            }
+        }
+        double amps_sum = 0.0;
+#pragma unroll
+        for (int c = 0; c < NS; c++) amps_sum += amps[c];
+        total_rate = row_allreduce_f64(amps_sum);                        // env.py:445
+
+        // ---- constraint excess of the pilots (env.py:449-452) ----
+        if (station_pilots) {
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) {
+                const unsigned s = (unsigned)j * 16u + q;
+                const unsigned info = st_info[s];
+                const float a = act_row[s];
+                const double ps = (live && s < n) ? legal_pilot((double)a * Consts::ACTION_SCALE_FACTOR, (info >> 7) != 0u) : 0.0;
+                unsigned mw[WORDS];
+                station_mulw(s, mw);
+#pragma unroll
+                for (int w = 0; w < WORDS; w++) pwords[w] = __umul24((unsigned)(int)ps, mw[w]) + pwords[w];
+            }
+        }
+        if (station_pilots || __ballot(live && !pilots_screened) != 0ull) {
+            if (!station_pilots) {
+#pragma unroll
+                for (int c = 0; c < NS; c++) {
+                    unsigned mw[WORDS];
+                    station_mulw(st[c], mw);
+#pragma unroll
+                    for (int w = 0; w < WORDS; w++) pwords[w] = __umul24((unsigned)(int)pilot[c], mw[w]) + pwords[w];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < WORDS; w++) pwords[w] = row_allreduce_u32(pwords[w]);
+            bool maybe = false;
+            if (q < m && !pilots_screened) maybe = !(quad_mag2_f32<WORDS>(net, q, pwords) < net.thr_p2[q]);
+            if (__builtin_expect(__ballot(maybe && live) != 0ull, 0)) {   // rare: exact evaluation
+                double ex = 0.0;
+                if (q < m) ex = fmax(row_mag_f64<WORDS>(net, (int)q, pwords, 1.0) - net.mag[q], 0.0);
+                excess = row_allreduce_f64(ex);
+            }
+        }
+
+        // ---- acnsim event pass at iteration t1: unplug (precedence 0) before plug-in (10) ----
+#pragma unroll
+        for (int c = 0; c < NS; c++)
+            if (valid[c] && dep[c] <= t1) { meta[c] = kEmptyMeta; rem[c] = 0.0; }
+        if (NS > 1) {                                   // entries sink to the lowest free slot of their lane
+#pragma unroll
+            for (int c = 1; c < NS; c++)
+                if (meta[c - 1] == kEmptyMeta && meta[c] != kEmptyMeta) {
+                    meta[c - 1] = meta[c]; rem[c - 1] = rem[c];
+                    meta[c] = kEmptyMeta; rem[c] = 0.0;
+                }
+        }
+        };
+        // the widest occupied slot of the wavefront picks the copy of the period's body
+        if (__builtin_expect(__ballot(meta[1] != kEmptyMeta || meta[2] != kEmptyMeta || meta[3] != kEmptyMeta) != 0ull, 0)) {
+            if (__ballot(meta[3] != kEmptyMeta) != 0ull) body(std::integral_constant<int, 4>{});
+            else if (__ballot(meta[2] != kEmptyMeta) != 0ull) body(std::integral_constant<int, 3>{});
+            else body(std::integral_constant<int, 2>{});
+        } else {
+            body(std::integral_constant<int, 1>{});
+        }
+
+        // ---- plug-ins of iteration t1 (sessions are sorted by arrival; the record at the cursor was fetched above) ----
+        if (live) t = t1;
+        while (__ballot(pending) != 0ull) {
+            const int s_dep = (int)(short)(sv.x >> 16);
+            const int s_est = (int)(short)(sv.y & 0xffffu);
+            const unsigned s_st = (sv.y >> 16) & 63u;
+            bool busy = false;
+#pragma unroll
+            for (int c = 0; c < kSlots; c++)
+                busy = busy || (pending && meta[c] != kEmptyMeta && (unsigned)entry_station(meta[c]) == s_st);
+            const bool row_busy = row_any(busy, row);
+            if (pending && row_busy) status |= EVC_STATUS_OCCUPIED;      // acnportal: StationOccupiedError
+            // the new entry takes the lowest free slot of the lowest free lane of its row (n <= 64 = 16 lanes x 4 slots:
+            // there is always one)
+            bool placed = !(pending && !row_busy);
+            const unsigned new_meta = pack_entry(s_dep, (int)s_st, s_est);
+#pragma unroll
+            for (int c = 0; c < kSlots; c++) {
+                if (__ballot(!placed) != 0ull) {
+                    const unsigned freebits = (unsigned)(__ballot(meta[c] == kEmptyMeta) >> (row * 16u)) & 0xffffu;
+                    const bool here = !placed && freebits != 0u;
+                    const unsigned tgt = (unsigned)__builtin_ctz(freebits | 0x10000u);
+                    if (here && q == tgt) { meta[c] = new_meta; rem[c] = rq; }
+                    placed = placed || here;
+                }
+            }
+            if (pending) {
+                cursor += 1;
+                sidx += 1u;
+                next_arrival = kNoArrival;
+            }
+            const bool more_ev = pending && cursor < n_sessions;
+            sv = buf_ld_v2(r_sess, more_ev ? sidx * 8u : kOob);
+            rq = buf_ld_f64(r_req, more_ev ? sidx * 8u : kOob);
+            if (more_ev) next_arrival = (int)(short)(sv.x & 0xffffu);
+            pending = more_ev && next_arrival <= t1;
+        }
+
+        // ---- reward (env.py:431-464), accumulators, episode return ----
+        const double profit = Consts::PROFIT_FACTOR * total_rate;
+        const double carbon = Consts::CARBON_COST_FACTOR * total_rate * moer_now;
+        const double excess_charge = excess * Consts::VIOLATION_FACTOR;
+        const bool done = live && t1 >= EVC_EPISODE_STEPS;
+        if (live) {
+            reward = profit - carbon - excess_charge;
+            ret += reward;
+            acc = acc + ((q == 0u) ? profit : (q == 1u ? carbon : excess_charge));
+            bd = acc;
+            done_last = done;
+        }
+        if (done) episodes += 1;
+
+        // ---- autoreset (gymnasium VectorEnv): terminal observation, then the next episode of the bank ----
+        const bool do_reset = done && P.autoreset;
+        if (__builtin_expect(__ballot(do_reset) != 0ull, 0)) {
+            if (io.out.final_obs) emit_obs(io.out.final_obs, do_reset);
+            if (do_reset) {
+                const int next = (slot + P.autoreset_stride) % P.bank_slots;
+                slot = next;
+                t = 0; cursor = 0;
+                const int first_arrival = (int)P.sessions[(size_t)next * P.max_sessions].arrival;
+                moer_day = P.slot_moer_day[next];
+                n_sessions = P.n_sessions[next];
+                next_arrival = n_sessions > 0 ? first_arrival : kNoArrival;
+#pragma unroll
+                for (int c = 0; c < kSlots; c++) { meta[c] = kEmptyMeta; rem[c] = 0.0; }
+                acc = 0.0;
+            }
+        }
+    }
+
+    // ---- registers -> memory: compact state, then the outputs of the last step ----
+    {
+        unsigned count = 0u;
+#pragma unroll
+        for (int c = 0; c < kSlots; c++) {
+            const bool alive = meta[c] != kEmptyMeta;
+            const unsigned bits = (unsigned)(__ballot(alive) >> (row * 16u)) & 0xffffu;
+            const unsigned pos = count + (unsigned)__popc(bits & ((1u << q) - 1u));
+            count += (unsigned)__popc(bits);
+            const bool w = ev && alive;
+            buf_st_u32(r_de, w ? (ebase + pos) * 4u : kOob, meta[c]);
+            buf_st_f64(r_rem, w ? (ebase + pos) * 8u : kOob, rem[c]);
+        }
+        buf_st_f64(r_acc, (ev && q < 3u) ? env * 24u + q * 8u : kOob, acc);
+        v4u o0, o1;
+        o0.x = (unsigned)t; o0.y = (unsigned)cursor; o0.z = (unsigned)slot; o0.w = (unsigned)moer_day;
+        o1.x = (unsigned)n_sessions; o1.y = (unsigned)next_arrival;
+        o1.z = ((unsigned)status & (unsigned)kStatusMask) | (count << kCountShift);
+        o1.w = (unsigned)episodes;
+        const unsigned so = (ev && q == 0u) ? env * 32u : kOob;
+        buf_st_v4(r_scal, so, o0);
+        buf_st_v4(r_scal, so == kOob ? kOob : so + 16u, o1);
+    }
+    if (io.steps > 0) {
+        if (__ballot(ever_live) != 0ull) emit_obs(io.out.obs, ever_live);
+        const rsrc_t r_rew = row_rsrc(io.out.reward, N * 8u);
+        const rsrc_t r_term = row_rsrc(io.out.terminated, N);
+        const rsrc_t r_bd = row_rsrc(io.out.breakdown, io.out.breakdown ? N * 24u : 0u);
+        buf_st_f64(r_rew, (ev && q == 0u) ? env * 8u : kOob, reward);
+        buf_st_u8(r_term, (ev && q == 0u) ? env : kOob, done_last ? 1 : 0);
+        buf_st_f64(r_bd, (ever_live && q < 3u) ? env * 24u + q * 8u : kOob, bd);
+        if (io.out.returns && ev && q == 0u) io.out.returns[env] = ret;
+    }
+}
+
+}  // namespace evc

@@ -507,23 +507,15 @@ __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, 
 #ifndef EVC_SOLVE_ENV_INLINE
 #define EVC_SOLVE_ENV_INLINE __forceinline__
 #endif
-// The projection + the rest of the step for ONE queued environment, by one wavefront (lane i: station i;
-// lane c: constraint row c; lane a: row a of the Newton system).  Shared by the slow kernel and by the
-// streaming kernel's in-kernel queue drain (evc_cquad.h).
-template <int WORDS>
-__device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io, SolverLds& L, int lane, int env, int wave_in_block = 0) {
+// The projection of ONE environment by one wavefront: lane i holds station i's target ln.b = 32 a and cap ln.h (amps);
+// returns the projected (and, where the solver moved it, tie-snapped) value of the lane's station.  `noconv` is set when
+// neither the Newton iteration nor the proximal-gradient safeguard reached the tolerance (EVC_STATUS_PROJ_NOCONV).
+// Shared by solve_env below (slow kernel, in-kernel drain) and by the fused rollout kernel (evc_rollout.h).
+__device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L, const LaneNet& lnet, SolverLane& ln, int lane,
+                                                   bool& noconv) {
     const int m = P.m, G = P.G;
-    const LaneNet lnet = lane_net(P, lane);
-    SolverLane ln;
-    ln.gid = lnet.gid;
+    noconv = false;
     [[maybe_unused]] long long c0 = SOLVER_CLK();
-    const EnvLoads cur = issue_loads(P, io, env, lane, wave_in_block);
-    EnvRegs r;
-    unpack_env(cur, r);
-    bool clamped;
-    const double a = unpack_action(io, cur, clamped);
-    ln.b = a * Consts::ACTION_SCALE_FACTOR;
-    ln.h = demand_cap_amps(r);
     if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; }
     SOLVER_SYNC();
 
@@ -743,12 +735,34 @@ __device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io
     SOLVER_STAT(6, n_act == 1 ? 1 : 0); SOLVER_STAT(7, (!converged && !last_ok) ? 1 : 0);
     if (!converged && !last_ok) {                 // rare: the Newton stalled — globally convergent fallback
         converged = solver_proximal_gradient(P, L, ln, lane);
-        if (!converged) r.status |= EVC_STATUS_PROJ_NOCONV;
+        if (!converged) noconv = true;
     }
     // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
     // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
     double y = ln.y;
     if (y != fmin(ln.b, ln.h)) y = tie_snap_counted(y, ln.h, lnet.is_cc, P.tie_counters);
+    return y;
+}
+
+// The projection + the rest of the step for ONE queued environment, by one wavefront (lane i: station i;
+// lane c: constraint row c; lane a: row a of the Newton system).  Shared by the slow kernel and by the
+// streaming kernel's in-kernel queue drain (evc_cquad.h).
+template <int WORDS>
+__device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io, SolverLds& L, int lane, int env, int wave_in_block = 0) {
+    const LaneNet lnet = lane_net(P, lane);
+    SolverLane ln;
+    ln.gid = lnet.gid;
+    const EnvLoads cur = issue_loads(P, io, env, lane, wave_in_block);
+    EnvRegs r;
+    unpack_env(cur, r);
+    bool clamped;
+    const double a = unpack_action(io, cur, clamped);
+    ln.b = a * Consts::ACTION_SCALE_FACTOR;
+    ln.h = demand_cap_amps(r);
+    bool noconv;
+    const double y = solve_projection(P, L, lnet, ln, lane, noconv);
+    if (noconv) r.status |= EVC_STATUS_PROJ_NOCONV;
+    [[maybe_unused]] long long c2 = SOLVER_CLK();
     finish_step<WORDS>(P, io, L.net, lnet, env, lane, y, clamped, cur.acc, false, r);
     SOLVER_STAT(14, SOLVER_CLK() - c2);
     SOLVER_SYNC();

@@ -1,0 +1,152 @@
+"""The fused rollout kernel (csrc/evc_rollout.h: T periods of a device-resident policy in one launch, state in
+registers) against (a) the same rollout as a loop of evc_step launches and (b) the oracle's episode loop
+(BaseAlgorithm.run, algorithms/base.py:63-88, under GreedyAlgorithm / RandomAlgorithm, baselines.py:22-51).
+Integers — event state, est_departures, terminated, statuses — bit-exact, remaining demands bit-exact against the
+step kernels, floats to 1e-9 against the oracle (north_star asks for 1e-5)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from sustaingym_amd.event_generation import gmm_device_tables
+from sustaingym_amd.hostio import to_host
+from sustaingym_amd.network import site_str_to_site
+
+pytestmark = pytest.mark.gpu
+
+
+def _gmm_engine(site, period, N, bank, seed, project=True, autoreset=False, **kw):
+    """Engine whose bank holds `bank` device-generated GMM days (the reference's own episode distribution)."""
+    from sustaingym_amd.engine import StepEngine
+    net = site_str_to_site(site)
+    tabs = gmm_device_tables(site, period)
+    eng = StepEngine(net, N, project_action=project, autoreset=autoreset, bank_slots=bank, max_sessions=128,
+                     moer_days=tabs['num_days'], **kw)
+    eng.upload_gmm(tabs)
+    eng.upload_moer(_moer_days(site, period))
+    eng.generate_episodes(0, bank, seed, 0)
+    return net, eng
+
+
+def _moer_days(site, period):
+    from sustaingym_amd.synthetic import synthetic_moer
+    return synthetic_moer(gmm_device_tables(site, period)['num_days'], seed=3)
+
+
+def _run(eng, policy, steps, bins, fused):
+    import torch
+    os.environ['EVC_ROLLOUT_FUSED'] = '1' if fused else '0'
+    try:
+        out = eng.rollout(policy=policy, steps=steps, bins=bins)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop('EVC_ROLLOUT_FUSED', None)
+    return {k: to_host(v).copy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize('site,policy,bins,project', [
+    ('caltech', 'random', 0, True), ('caltech', 'greedy', 0, True), ('jpl', 'random', 0, True),
+    ('jpl', 'greedy', 0, True), ('caltech', 'random', 5, True), ('caltech', 'random', 0, False),
+    ('jpl', 'greedy', 0, False)])
+def test_fused_rollout_equals_the_loop_of_steps(site, policy, bins, project):
+    """One launch of T periods == T launches of one period: every piece of simulator state and every output,
+    for T = 1, a stretch of the congested morning, a whole day, and across an autoreset boundary."""
+    N, bank = 1022, 2048                      # not a multiple of 4: the last quad is ragged
+    period = 'Summer 2019' if site == 'caltech' else 'Summer 2021'
+    engines = []
+    for fused in (True, False):
+        net, eng = _gmm_engine(site, period, N, bank, seed=77, project=project, autoreset=True)
+        eng.set_autoreset_stride(N)
+        eng.set_policy_seed(99, env_id_base=5000)
+        eng.reset()
+        engines.append(eng)
+    n = net.num_stations
+    total = 0
+    for steps in (1, 95, 60, 132, 40, 300):       # 1 + 95 + 60 + 132 = 288: the fourth call ends ON the boundary
+        a = _run(engines[0], policy, steps, bins, True)
+        b = _run(engines[1], policy, steps, bins, False)
+        total += steps
+        tag = f'{site} {policy} after {total} steps'
+        sa, sb = engines[0].get_state(), engines[1].get_state()
+        assert np.array_equal(sa['scalars'], sb['scalars']), tag
+        assert np.array_equal(sa['departure'], sb['departure']), tag
+        assert np.array_equal(sa['est_departure'], sb['est_departure']), tag
+        assert np.array_equal(sa['remaining_kwh'], sb['remaining_kwh']), tag            # same doubles
+        np.testing.assert_allclose(sa['breakdown'], sb['breakdown'], rtol=1e-12, atol=1e-13, err_msg=tag)
+        assert np.array_equal(a['terminated'], b['terminated']), tag
+        assert np.array_equal(a['obs'], b['obs']), tag
+        assert np.array_equal(a['final_obs'], b['final_obs']), tag
+        np.testing.assert_allclose(a['reward'], b['reward'], rtol=1e-12, atol=1e-14, err_msg=tag)
+        np.testing.assert_allclose(a['breakdown'], b['breakdown'], rtol=1e-12, atol=1e-13, err_msg=tag)
+        np.testing.assert_allclose(a['returns'], b['returns'], rtol=1e-12, atol=1e-13, err_msg=tag)
+    assert (sa['scalars'][:, 7] >= 2).all()               # two episodes finished everywhere
+    assert not (sa['scalars'][:, 6] & 2).any()            # EVC_STATUS_PROJ_NOCONV never
+    for eng in engines:
+        eng.close()
+
+
+@pytest.mark.parametrize('site,policy,bins', [('caltech', 'greedy', 0), ('caltech', 'random', 0),
+                                              ('jpl', 'greedy', 0), ('jpl', 'random', 0), ('caltech', 'random', 5)])
+def test_fused_rollout_16384_gmm_days_against_the_oracle(site, policy, bins):
+    """whole GMM days at 16 384 environments under greedy / random — episode returns, reward
+    breakdowns, the last step's outputs and the final station state equal the oracle's episode loop."""
+    N = 16384
+    period = 'Summer 2019' if site == 'caltech' else 'Summer 2021'
+    net, eng = _gmm_engine(site, period, N, N, seed=1234)
+    n = net.num_stations
+    ns, sess, req, day, _ = eng.download_episodes(0, N)
+    bat = ob.OracleBatch(ob.OracleNetwork(net), N, 36, True)
+    bat.set_bank(ns, sess, req, day, _moer_days(site, period))
+    eng.set_policy_seed(4321, env_id_base=70000)
+    obs0 = to_host(eng.reset()).copy()
+    assert np.array_equal(obs0, bat.reset())
+    steps = 288
+    g = _run(eng, policy, steps, bins, True)
+    o = bat.rollout(policy, obs0, steps=steps, bins=bins, seed=4321, env_id_base=70000)
+    assert g['terminated'].all() and o['terminated'].all()
+    np.testing.assert_allclose(g['returns'], o['returns'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(g['breakdown'], o['breakdown'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(g['reward'], o['reward'], rtol=1e-9, atol=1e-13)
+    assert np.array_equal(g['obs'][:, n:], o['obs'][:, n:])                     # est_departures, MOER, timestep
+    np.testing.assert_allclose(g['obs'][:, :n], o['obs'][:, :n], rtol=2e-7, atol=0)
+    rem, dep, est = eng.station_state()
+    o_rem, o_dep, o_est = bat.station_state()
+    assert np.array_equal(dep, o_dep) and np.array_equal(est, o_est)
+    np.testing.assert_allclose(rem, o_rem, rtol=1e-9, atol=1e-10)
+    sc = eng.env_scalars()
+    assert (sc['t'] == 288).all() and (sc['episodes'] == 1).all()
+    assert np.array_equal(sc['status'] != 0, o['status'] != 0)
+    assert not (sc['status'] & 2).any()
+    assert g['returns'].std() > 0
+    eng.close()
+
+
+def test_fused_rollout_mid_episode_and_after_done():
+    """A rollout that starts mid-episode from a state the step kernel left, runs past the end of the episode
+    without autoreset (steps after termination are ignored and flagged), and a zero-demand corner."""
+    from helpers import make_workload, make_pair
+    from sustaingym_amd.network import caltech_acn
+    from sustaingym_amd.hostio import to_device
+    net = caltech_acn()
+    N, n = 130, net.num_stations
+    wl = make_workload(net, N, seed=5, busy=True)
+    eng, bat = make_pair(net, N, wl, True, debug=False)
+    obs = to_host(eng.reset()).copy()
+    assert np.array_equal(obs, bat.reset())
+    rng = np.random.default_rng(3)
+    for t in range(100):                                   # 100 ordinary steps first
+        a = rng.random((N, n), dtype=np.float32)
+        g = eng.step(to_device(a))
+        o = bat.step(a, debug=False)
+    obs = o['obs']
+    assert np.array_equal(to_host(g['obs'])[:, n:], obs[:, n:])
+    gg = _run(eng, 'greedy', 250, 0, True)                 # 188 live steps + 62 after termination
+    oo = bat.rollout('greedy', obs, steps=250)
+    np.testing.assert_allclose(gg['returns'], oo['returns'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gg['breakdown'], oo['breakdown'], rtol=1e-9, atol=1e-12)
+    assert gg['terminated'].all() and (gg['reward'] == 0).all()
+    sc = eng.env_scalars()
+    assert (sc['status'] & 4).all() and (sc['t'] == 288).all()       # EVC_STATUS_STEP_AFTER_DONE
+    assert np.array_equal(gg['obs'][:, n:], oo['obs'][:, n:])
+    eng.close()

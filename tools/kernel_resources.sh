@@ -3,9 +3,8 @@
 # in the built library (reads the code object's metadata; no GPU needed).
 LIB=${1:-sustaingym_amd/libevcharge_hip.so}
 T=$(mktemp -d)
-objcopy -O binary --only-section=.hip_fatbin "$LIB" $T/fat.bin
-/opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$T/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/dev.co
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes $T/dev.co | python3 -c "
+"$(dirname "$0")/unbundle.sh" "$LIB" $T
+for co in $T/dev_*.co; do /opt/rocm/lib/llvm/bin/llvm-readelf --notes $co; done | python3 -c "
 import re, subprocess, sys
 txt = sys.stdin.read()
 rows = []
@@ -14,7 +13,7 @@ for blk in txt.split('- .agpr_count')[1:]:
     g = lambda k: int(re.search(r'\.' + k + r':\s+(\d+)', blk).group(1))
     ag = int(re.match(r':\s+(\d+)', blk).group(1))
     dem = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
-    dem = dem.replace('void evc::', '').replace('(evc::Params, evc::StepIO)', '')
+    dem = dem.replace('void evc::', '').replace('(evc::Params, evc::StepIO)', '').replace('(evc::Params, evc::RolloutIO)', '')
     rows.append((dem, g('vgpr_count'), ag, g('sgpr_count'), g('vgpr_spill_count'), g('sgpr_spill_count'), g('group_segment_fixed_size'), g('private_segment_fixed_size')))
 flt = re.compile(sys.argv[1]) if len(sys.argv) > 1 else None
 print(f'{\"kernel\":<52} vgpr agpr sgpr vspill sspill    lds scratch')
