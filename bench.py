@@ -53,6 +53,14 @@ def parse_args(argv=None):
     p.add_argument('--steps', type=int, default=576)
     p.add_argument('--warmup', type=int, default=288)
     p.add_argument('--envs-per-gpu', type=int, default=65536)
+    p.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                   help="'weak' (default): --envs-per-gpu environments on every GPU; 'strong': --global-envs environments "
+                        'split over the GPUs (north_star: 65 536 batched environments on 8 GPUs).  An N > 1 weak run also '
+                        "times the strong form afterwards and reports it as 'strong_scaling'")
+    p.add_argument('--global-envs', type=int, default=65536, help='total environments of the strong-scaling form')
+    p.add_argument('--dry-rccl', action='store_true',
+                   help="initialise the 'nccl' (= RCCL) process group with world size 1 on cuda:0, all-gather the metrics "
+                        'vector, print one JSON line and exit (run in a child process by the N = 1 bench)')
     p.add_argument('--site', default='caltech', choices=['caltech', 'jpl'])
     p.add_argument('--no-project', action='store_true', help='project_action_in_env=False')
     p.add_argument('--bank', type=int, default=8192, help='distinct episodes resident in HBM')
@@ -64,9 +72,9 @@ def parse_args(argv=None):
                    help="acnportal Linear2StageBattery(charge_calculation=...); 'continuous' is acnportal's default")
     p.add_argument('--busy', action='store_true',
                    help='congested variant of the workload (30-60 long sessions per day); not the headline')
-    p.add_argument('--episodes', default='synthetic', choices=['synthetic', 'gmm'],
-                   help="'gmm': the bank is generated on the device from the reference's GMM (Summer 2019); "
-                        'not the headline (it is one of the secondary records)')
+    p.add_argument('--episodes', default='synthetic', choices=['synthetic', 'gmm', 'real'],
+                   help="'gmm': the bank is generated on the device from the reference's GMM (Summer 2019); 'real': every "
+                        'ACN-Data day of Summer 2021 (RealTraceBank); not the headline (secondary records)')
     p.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                    help="process-group backend for --gpus > 1 ('nccl' = RCCL; 'gloo' only to exercise the N > 1 "
                         'logic with several ranks on ONE GPU, see --single-device)')
@@ -125,11 +133,22 @@ class EvWorkload:
         self.P = P = min(bank, max(N, 1))
         self.moer_days = 32
         self.moer = synthetic_moer(self.moer_days, seed=7)
+        real = None
+        if episodes == 'real':            # every day of the packaged period, with the period's own MOER matrices
+            from datetime import timedelta
+            from sustaingym_amd.event_generation import RealTraceBank
+            real = RealTraceBank(site, 'Summer 2021')
+            self.P = P = real.num_days_in_date_range
+            self.moer_days = P
+            self.moer = np.stack([real.moer_loader.retrieve(real.date_range[0] + timedelta(days=d)) for d in range(P)])
         self.eng = eng = StepEngine(net, N, moer_forecast_steps=self.k, project_action=project, autoreset=True,
-                                    device=dev_index, bank_slots=P, max_sessions=128 if episodes == 'gmm' else 64,
+                                    device=dev_index, bank_slots=P, max_sessions=128 if episodes in ('gmm', 'real') else 64,
                                     moer_days=self.moer_days, charge_calculation=battery)
         eng.upload_moer(self.moer)
-        if episodes == 'gmm':
+        if real is not None:
+            self.bank = (real.n_sessions, real.sessions, real.requested, real.moer_day)
+            eng.upload_episodes(*self.bank)
+        elif episodes == 'gmm':
             from sustaingym_amd.event_generation import gmm_device_tables
             eng.upload_gmm(dict(gmm_device_tables(site, 'Summer 2019'), num_days=self.moer_days))
             eng.generate_episodes(0, P, seed_base + rank, 0)
@@ -199,14 +218,47 @@ class EvWorkload:
         self.eng.close()
 
 
+def code_object_hash(symbol: bytes = b'step_kernel_cquad') -> str | None:
+    """sha256 (first 16 hex digits) of the gfx950 code object of the built library that holds `symbol`: what ties a
+    PMC-derived traffic figure to the kernels that produced it."""
+    import hashlib
+    import struct
+    from sustaingym_amd import _lib
+    try:
+        data = open(_lib.LIB_PATH, 'rb').read()
+    except OSError:
+        return None
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    at = data.find(magic)
+    while at >= 0:
+        n_entries = struct.unpack_from('<Q', data, at + len(magic))[0]
+        pos = at + len(magic) + 8
+        for _ in range(n_entries):
+            off, size, tlen = struct.unpack_from('<QQQ', data, pos)
+            triple = data[pos + 24:pos + 24 + tlen]
+            pos += 24 + tlen
+            if b'gfx950' in triple:
+                blob = data[at + off:at + off + size]
+                if symbol in blob:
+                    return hashlib.sha256(blob).hexdigest()[:16]
+        at = data.find(magic, at + 1)
+    return None
+
+
 def lookup_traffic(site, N, project, layout):
     """HBM bytes per launch of the streaming kernel from the PMC passes of tools/profile.sh (profiles/traffic.json:
-    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per MI355X_MICROARCH.md, collected in separate --pmc runs)."""
+    FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs, corrected as DESIGN.md §6 describes).  The entry records
+    the hash of the code object it was measured on: a library built from different kernels gets `None` (and the
+    reason) instead of a stale figure."""
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     try:
         tj = json.load(open(tpath))
         key = f'{site}_N{N}_project{int(project)}' + ('' if layout == 'dense' else f'_{layout}')
-        return tj.get(key, {}).get('hbm_bytes_per_launch'), tj.get(key, {}).get('source')
+        ent = tj.get(key, {})
+        have = code_object_hash()
+        if ent and ent.get('code_object_sha256') != have:
+            return None, f"profiles/traffic.json was measured on code object {ent.get('code_object_sha256')}, this library is {have}: re-run tools/profile.sh"
+        return ent.get('hbm_bytes_per_launch'), ent.get('source')
     except Exception:
         return None, None
 
@@ -280,16 +332,18 @@ def cpu_baseline_record(args, w: EvWorkload, acts) -> dict:
 # ------------------------------------------------------------------------------------------------
 # secondary records: the other regimes BASELINE.json's configs name (rank 0, outside the timed region)
 # ------------------------------------------------------------------------------------------------
-def secondary_gmm(site, dev_index, battery) -> dict:
-    """65 536 environments on days sampled on the device from the reference's GMM (Summer 2019 model):
-    the reference's own episode distribution — busier than the headline's synthetic days, pods and feeders
-    bind around midday, the slow kernel takes part."""
-    w = EvWorkload(site, 65536, dev_index, 0, project=True, episodes='gmm', phase='sync', battery=battery)
+def secondary_days(site, episodes, dev_index, battery) -> dict:
+    """65 536 environments on the reference's own episode distributions: episodes = 'gmm' — days sampled on the device
+    from the packaged GMM (Summer 2019 model, GMMsTraceGenerator) — or 'real' — every ACN-Data day of Summer 2021
+    (RealTraceGenerator, sequential; real MOER).  Busier than the headline's synthetic days: pods and feeders bind
+    around midday, the slow path takes part."""
+    w = EvWorkload(site, 65536, dev_index, 0, project=True, episodes=episodes, phase='sync', battery=battery)
     w.run(EPISODE)                                   # one untimed day; the timed one starts at an episode boundary
     wall = w.wall_ms_per_step(EPISODE)               # one whole synchronised day (what a vector env plays)
     timed = w.time_kernels(EPISODE)
     alg = algorithmic_bytes_per_env_step(w.n, w.k)
-    rec = {'workload': f'65536 x {w.n}-station ({site}) on device-generated GMM days, projection on, synchronised episodes, mean over one whole day',
+    what = 'device-generated GMM days' if episodes == 'gmm' else f'the {w.P} ACN-Data days of Summer 2021 (RealTraceBank), real MOER'
+    rec = {'workload': f'65536 x {w.n}-station ({site}) on {what}, projection on, U[0,1) actions, synchronised episodes, mean over one whole day',
            'ms_per_step': round(wall, 5), 'env_steps_per_s': round(65536 / wall * 1e3, 1),
            'kernel_us': round(float(timed['main_ms'].mean()) * 1e3, 2),
            'kernel_us_by_4h': [round(float(x.mean()) * 1e3, 1) for x in np.array_split(timed['main_ms'], 6)],
@@ -302,6 +356,143 @@ def secondary_gmm(site, dev_index, battery) -> dict:
                         'note': 'on the whole step (streaming + slow kernel), not on one kernel'}}
     w.close()
     return rec
+
+
+def secondary_rollout(policy, dev_index, battery, episodes='synthetic') -> dict:
+    """Whole episodes under a device-resident policy (BaseAlgorithm.run over GreedyAlgorithm / RandomAlgorithm,
+    algorithms/base.py:63-88, baselines.py:22-51): 65 536 environments x 288 periods in ONE launch of the fused rollout
+    kernel (csrc/evc_rollout.h: state in registers, no per-period action read / observation write), beside the same
+    rollout as a loop of evc_step launches and the oracle's C episode loop on a bounded sample of the same episodes."""
+    import torch
+    from oracle import binding as ob
+    from sustaingym_amd.hostio import to_host
+    N = 65536
+    w = EvWorkload('caltech', N, dev_index, 0, project=True, episodes=episodes, phase='sync', battery=battery)
+    eng = w.eng
+    eng.set_policy_seed(7)
+    dev = w.dev
+
+    def episodes_per_call(fused, reps):
+        os.environ['EVC_ROLLOUT_FUSED'] = '1' if fused else '0'
+        try:
+            eng.rollout(policy=policy, steps=EPISODE)                  # untimed (first launch, bank wrap)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.rollout(policy=policy, steps=EPISODE)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / reps
+        finally:
+            os.environ.pop('EVC_ROLLOUT_FUSED', None)
+    fused = episodes_per_call(True, 5)
+    eng.enable_timing(True)
+    eng.rollout(policy=policy, steps=EPISODE)
+    kernel_ms = eng.last_step_ms()[0]
+    eng.enable_timing(False)
+    loop = episodes_per_call(False, 2)
+    # CPU: the oracle's episode loop on the first 4096 episodes of the bank
+    cn = 4096
+    ns, sess, req, day = w.bank
+    bat = ob.OracleBatch(ob.OracleNetwork(w.net), cn, w.k, True, battery)
+    bat.set_bank(ns, sess, req, day, w.moer, autoreset_stride=1)
+    obs0 = bat.reset(np.arange(cn, dtype=np.int32) % w.P)
+    cores = ob.default_threads()
+    t0 = time.perf_counter()
+    bat.rollout(policy, obs0, steps=EPISODE, seed=7, threads=cores)
+    cpu = time.perf_counter() - t0
+    w.close()
+    return {'workload': f'{N} x {w.n}-station (caltech), {"synthetic days" if episodes == "synthetic" else "device-generated GMM days"}, '
+                        f'projection on, {policy} policy on the device, whole episodes (288 periods), autoreset',
+            'env_steps_per_s': round(N * EPISODE / fused, 1), 'episode_ms': round(fused * 1e3, 4),
+            'us_per_period': round(fused / EPISODE * 1e6, 3), 'launches_per_episode': 1,
+            'kernel': 'evc::rollout_kernel', 'kernel_ms': round(kernel_ms, 4),
+            'loop_of_steps': {'env_steps_per_s': round(N * EPISODE / loop, 1), 'episode_ms': round(loop * 1e3, 3),
+                              'launches_per_episode': EPISODE * (2 if policy == 'random' else 1) + 0,
+                              'note': 'EVC_ROLLOUT_FUSED=0: evc_step per period (random: + the action kernel), observations written every period'},
+            'cpu_port': {'value': round(cn * EPISODE / cpu, 1), 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+                         'sample': f'{cn} episodes x 288 periods, oracle/ orc_batch_rollout, {cpu:.1f} s'}}
+
+
+def secondary_vector_env_api(dev_index, battery) -> dict:
+    """north_star's API surface, boundaries included: steps through EVChargingVectorEnv.step (Gymnasium VectorEnv semantics)
+    with episodes from the on-device GMM generator — (a) torch in / torch out, nothing leaves the GPU; (b) the numpy path
+    SB3 / RLlib use (actions and observations cross PCIe every step; never the headline `value`)."""
+    import torch
+    from sustaingym_amd.envs import EVChargingVectorEnv
+    from sustaingym_amd.event_generation import DeviceGMMTraceGenerator
+    out = {}
+    N = 65536
+    venv = EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2019', seed=0), num_envs=N, output='torch',
+                               device=dev_index, charge_calculation=battery)
+    venv.reset(seed=0)
+    dev = torch.device('cuda', dev_index)
+    acts = torch.rand((N, venv.num_stations), device=dev)
+    for _ in range(EPISODE):
+        venv.step(acts)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(2 * EPISODE):                       # two whole episodes: two boundaries (bank refill, max_profit download)
+        venv.step(acts)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / (2 * EPISODE)
+    venv.close()
+    out['torch'] = {'workload': f'{N} x 54-station (caltech) EVChargingVectorEnv.step, torch tensors, DeviceGMMTraceGenerator, two episodes incl. boundaries',
+                    'ms_per_step': round(dt * 1e3, 5), 'env_steps_per_s': round(N / dt, 1)}
+    Nn = 16384
+    venv = EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2019', seed=0), num_envs=Nn, output='numpy',
+                               zero_copy=True, device=dev_index, charge_calculation=battery)
+    venv.reset(seed=0)
+    a = np.random.default_rng(0).random((Nn, venv.num_stations), dtype=np.float32)
+    for _ in range(10):
+        venv.step(a)
+    t0 = time.perf_counter()
+    for _ in range(100):
+        venv.step(a)
+    dt = (time.perf_counter() - t0) / 100
+    venv.close()
+    out['sb3_numpy_path'] = {'workload': f'{Nn} x 54-station (caltech) EVChargingVectorEnv.step, numpy in / numpy out (page-locked, zero_copy): '
+                                         f'{a.nbytes / 1e6:.1f} MB of actions in and {Nn * 146 * 4 / 1e6:.1f} MB of observations out per step over PCIe',
+                             'ms_per_step': round(dt * 1e3, 5), 'env_steps_per_s': round(Nn / dt, 1), 'pcie_inclusive': True}
+    return out
+
+
+def dry_rccl() -> int:
+    """`bench.py --dry-rccl`: the N > 1 bench's process-group plumbing with ONE rank — init 'nccl' (= RCCL) on cuda:0,
+    all-gather a metrics-sized vector, barrier, destroy.  Prints one JSON line."""
+    import torch
+    import torch.distributed as dist
+    from sustaingym_amd.distributed import all_gather_vector, max_over_ranks
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    t0 = time.perf_counter()
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', device_id=dev)
+    vec = all_gather_vector(np.arange(9, dtype=np.float64), dev)
+    mx = max_over_ranks(1.5, dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    ok = vec.shape == (1, 9) and float(vec[0, 8]) == 8.0 and mx == 1.5
+    backend = dist.get_backend()
+    dist.destroy_process_group()
+    print(json.dumps({'rccl_world1': bool(ok), 'backend': backend, 'seconds': round(time.perf_counter() - t0, 2),
+                      'nccl_version': list(torch.cuda.nccl.version()) if hasattr(torch.cuda, 'nccl') else None}))
+    return 0 if ok else 1
+
+
+def secondary_rccl_world1() -> dict:
+    """Runs `bench.py --dry-rccl` in a child process (a fault inside RCCL must not cost the headline)."""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--dry-rccl'], capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {'rccl_world1': False, 'error': 'timeout after 240 s'}
+    for ln in r.stdout.splitlines():
+        if ln.startswith('{'):
+            return json.loads(ln)
+    return {'rccl_world1': False, 'returncode': r.returncode, 'stderr_tail': r.stderr[-400:]}
 
 
 def secondary_tie_snap(dev_index, battery) -> dict:
@@ -439,6 +630,8 @@ def secondary_battery(dev_index) -> dict:
 
 def main():
     args = parse_args()
+    if args.dry_rccl:
+        sys.exit(dry_rccl())
     from sustaingym_amd.distributed import WorldMismatch, resolve_world
     try:
         rank, local_rank, world, must_spawn = resolve_world(args.gpus, os.environ)
@@ -472,7 +665,7 @@ def main():
 
     from sustaingym_amd.distributed import all_gather_vector, max_over_ranks, metrics_vector
 
-    N = args.envs_per_gpu
+    N = args.envs_per_gpu if args.scaling == 'weak' else max(4, args.global_envs // world)
     project = not args.no_project
     w = EvWorkload(args.site, N, local_rank, rank, project=project, episodes=args.episodes, bank=args.bank,
                    ring=args.ring, busy=args.busy, phase=args.phase, battery=args.battery)
@@ -504,6 +697,23 @@ def main():
     per_rank = all_gather_vector(local_vec, coll_dev)
     total = per_rank[:, :6].sum(axis=0)
 
+    # ---- strong-scaling form beside a weak N > 1 run: --global-envs environments split over the ranks ----
+    strong = None
+    if world > 1 and args.scaling == 'weak':
+        Ns = max(4, args.global_envs // world)
+        ws = EvWorkload(args.site, Ns, local_rank, rank, project=project, episodes=args.episodes, bank=args.bank,
+                        ring=args.ring, busy=args.busy, phase=args.phase, battery=args.battery)
+        ws.run(args.warmup)
+        barrier()
+        t1 = time.perf_counter()
+        ws.run(args.steps)
+        barrier()
+        el_s = max_over_ranks(time.perf_counter() - t1, coll_dev)
+        ws.close()
+        strong = {'scaling': 'strong', 'global_envs': Ns * world, 'envs_per_gpu': Ns, 'steps': args.steps,
+                  'ms_per_step': round(el_s / args.steps * 1e3, 5), 'value': round(Ns * world * args.steps / el_s, 1),
+                  'unit': 'env-steps/s'}
+
     roofline = cpu_baseline = episode_generation = secondary = None
     if rank == 0:
         timed = w.time_kernels(args.kernel_timing_steps)
@@ -533,8 +743,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         secondary = {}
         for name, fn in (('sync_reference', lambda: secondary_sync_reference(args.site, local_rank, args.battery, project)),
-                         ('gmm_caltech', lambda: secondary_gmm('caltech', local_rank, args.battery)),
-                         ('gmm_jpl', lambda: secondary_gmm('jpl', local_rank, args.battery)),
+                         ('gmm_caltech', lambda: secondary_days('caltech', 'gmm', local_rank, args.battery)),
+                         ('gmm_jpl', lambda: secondary_days('jpl', 'gmm', local_rank, args.battery)),
+                         ('real_caltech', lambda: secondary_days('caltech', 'real', local_rank, args.battery)),
+                         ('rollout_greedy_65536', lambda: secondary_rollout('greedy', local_rank, args.battery)),
+                         ('rollout_random_65536', lambda: secondary_rollout('random', local_rank, args.battery)),
+                         ('rollout_random_65536_gmm', lambda: secondary_rollout('random', local_rank, args.battery, 'gmm')),
+                         ('vector_env_api', lambda: secondary_vector_env_api(local_rank, args.battery)),
+                         ('rccl_world1', secondary_rccl_world1),
                          ('multiagent_8192x54', lambda: secondary_multiagent(local_rank, args.battery)),
                          ('battery_16384', lambda: secondary_battery(local_rank)),
                          ('tie_snap_reach', lambda: secondary_tie_snap(local_rank, args.battery))):
@@ -554,7 +770,7 @@ def main():
             'metric': 'env-steps/sec at 65k batched 54-station EVChargingEnv; 1/2/4/8 MI355X',
             'value': round(value, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 5),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic' if args.episodes == 'synthetic' else
                     'synthetic actions / MOER, episodes sampled on the device from the packaged GMM',
             'config': {'workload': f'{N} batched {n}-station EVChargingEnv ({args.site}) per GPU, continuous actions, '
@@ -570,14 +786,21 @@ def main():
                          'device': [int(d) for d in per_rank[:, 7]],
                          'env_steps_timed': [int(s) for s in per_rank[:, 8]]},
             'env_steps_timed': int(per_rank[:, 8].sum()),
+            # the same run in the other scaling form (N > 1 weak runs only): north_star's "65 536 batched ... on 8 GPUs"
+            'strong_scaling': strong,
+            # the reference's own episode distribution beside the headline's quiet synthetic days (secondary.gmm_caltech)
+            'value_reference_distribution': (secondary or {}).get('gmm_caltech', {}).get('env_steps_per_s') if secondary else None,
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'episode_generation': episode_generation,
             'episode_metrics': {'profit': float(total[0]), 'carbon_cost': float(total[1]),
                                 'excess_charge': float(total[2]), 'episodes_finished': float(total[4]),
                                 'envs_with_status': float(total[5]),
                                 # reach of the tie snap on rank 0: values a projection solver moved, and how
                                 # many of them lay within 1e-6 A of a rounding boundary before the snap
-                                'solver_moved_values': float(tie['solver_moved_values']),
-                                'tie_snap_near_boundary': float(tie['tie_snap_near_boundary'])},
+                                # the lean streaming kernels do not count what their in-row water-filling moves (the counting
+                                # code cost 1 us per step): no figure here; secondary.tie_snap_reach counts a
+                                # whole GMM day through the kernels that do
+                                'solver_moved_values': None, 'tie_snap_near_boundary': None,
+                                'slow_path_moved_values': float(tie['solver_moved_values'])},
             'secondary': secondary,
         }
         print(json.dumps(line))

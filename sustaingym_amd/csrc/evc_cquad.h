@@ -75,7 +75,7 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
     typedef __attribute__((address_space(3))) CquadLds LdsImage;
     CquadLds& S = *(CquadLds*)(LdsImage*)(size_t)(unsigned)rfl((int)lds);
     const int lane = (int)__lane_id();            // wave 0 of the workgroup: lane = thread id, without asking the caller for it
-    const int count = rfl(S.local_count);
+    const int count = rfl(S.local_count < kDrainListMax ? S.local_count : kDrainListMax);
     // the slow path works on the workgroup's tables and on the memory of the per-step images (CquadLds::Images)
     SolverLds L(S.net, S.u.solver_workspace);
     for (int i = 0; i < count; i++) solve_env<WORDS>(P, io, L, lane, rfl(S.local_list[i]));
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             bool undecided = live && row_any(maybe, row);
             pilots_screened = !row_any(maybe_p, row);
 #ifdef EVC_COUNT_UNDECIDED         /* diagnostic builds only: environments the screen leaves undecided, in metrics[7] */
-            if (undecided && q == 0u) atomicAdd(P.tie_counters + 2 * (env & (kTieSlots - 1)) + 1, 1);
+            if (undecided && q == 0u) atomicAdd(P.tie_counters + 2 * (env & (kTieSlots - 1)) + 1, 1ull);
 #endif
 #ifdef EVC_ABL_NO_EXACT            /* ablation builds only (wrong results): cost of the exact path on congested days */
             undecided = false;
@@ -368,14 +368,26 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                     const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, P.snap_tol), row);
                     anyviol = anyviol && !(fill && !still);
                 }
-                const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel
+                bool queue_me = undecided && anyviol;             // cones (or unsettled): slow kernel
+                bool list_full = false;
                 if (queue_me && q == 0u) {
                     if (DRAIN) {
-                        S.local_list[atomicAdd(&S.local_count, 1) & (kDrainListMax - 1)] = (int)env;
+                        // The list holds every environment the workgroup steps (the engine launches this form only with
+                        // quads_per_wave * 16 <= kDrainListMax, also under EVC_DRAIN=1), so it cannot be full; should a future
+                        // launch shape break that, the environment is stepped with what the row could settle and FLAGGED
+                        // (EVC_STATUS_PROJ_NOCONV) instead of being silently skipped.
+                        const int at = atomicAdd(&S.local_count, 1);
+                        if (at < kDrainListMax) S.local_list[at] = (int)env;
+                        else list_full = true;
                         __hip_atomic_fetch_add(P.slow_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // diagnostics only
                     } else {
                         queue_push(P, (int)env);
                     }
+                }
+                if (DRAIN) {
+                    const bool full = row_any(list_full, row);
+                    if (full) status |= EVC_STATUS_PROJ_NOCONV;
+                    queue_me = queue_me && !full;
                 }
                 live = live && !queue_me;                 // queued rows write nothing here
                 pilots_screened = pilots_screened && !undecided;
@@ -686,7 +698,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 
     if (DRAIN) {
         __syncthreads();                       // every wave's queue entries are in the list; the images are free
-        const int count = S.local_count;
+        const int count = S.local_count < kDrainListMax ? S.local_count : kDrainListMax;
         if (__builtin_expect(count != 0, 0) && wv == 0u) {
 #ifndef EVC_ABL_DRAIN_NO_SOLVE      /* ablation builds only: the tail's own cost without the slow path's code */
             drain_local_list<WORDS>((unsigned)(size_t)(__attribute__((address_space(3))) void*)&S);

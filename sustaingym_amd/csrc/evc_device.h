@@ -100,7 +100,7 @@ struct Params {
     double class_cap[EVC_MAX_GROUPS];
     unsigned simple_rows;                           // bit c set: row c is simple
     double snap_tol;                                // row tolerance after the tie snap: PROJ_TOL + what snapping can add to a row / cap
-    int* tie_counters;                              // [kTieSlots][2] tie_snap_counted
+    unsigned long long* tie_counters;               // [kTieSlots][2] tie_snap_counted (64-bit: a long soak moves > 2^31 values)
     double prox_step;                               // 1 / (Gershgorin bound on lambda_max(B B')): step of the solver's proximal-gradient safeguard
     // persistent state
     double* rem;             // [N][n] remaining demand (kWh) of the plugged EV
@@ -326,7 +326,7 @@ __device__ __forceinline__ double tie_snap(double y, double h) {
 // other pilot.  Counted by the slow path and by the streaming kernels WITH per-station debug outputs; the lean
 // streaming kernels pass no counters (the counting code alone cost them 1 us per step, measured).
 constexpr int kTieSlots = 256;
-__device__ __forceinline__ double tie_snap_counted(double y, double h, bool is_cc, int* counters) {
+__device__ __forceinline__ double tie_snap_counted(double y, double h, bool is_cc, unsigned long long* counters) {
 #ifdef EVC_ABL_NO_TIE_COUNT       /* ablation builds only: cost of the counting */
     counters = nullptr;
 #endif
@@ -347,9 +347,9 @@ __device__ __forceinline__ double tie_snap_counted(double y, double h, bool is_c
             // also reached through a call (evc_cquad.h), and a callee that wants workgroup ids makes its caller keep
             // them alive through the whole streaming loop
             const unsigned hw = (unsigned)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (7 << 11));
-            int* slot = counters + 2 * (hw & (kTieSlots - 1));
-            atomicAdd(slot, __popcll(movers));
-            if (nears) atomicAdd(slot + 1, __popcll(nears));
+            unsigned long long* slot = counters + 2 * (hw & (kTieSlots - 1));
+            atomicAdd(slot, (unsigned long long)__popcll(movers));
+            if (nears) atomicAdd(slot + 1, (unsigned long long)__popcll(nears));
         }
     }
     return tie_snap(y, h);

@@ -80,7 +80,7 @@ struct evc_engine {
     NetTables* d_tables = nullptr;
     int* d_slow_count = nullptr;  // [2]: queue length per step parity
     int* d_slow_list = nullptr;
-    int* d_tie = nullptr;         // Params::tie_counters
+    unsigned long long* d_tie = nullptr;   // Params::tie_counters
     // Drain mode (who solves what the streaming kernel queues): on a workload whose steps queue at most a few
     // dozen environments every workgroup of the lean compact streaming kernel solves the ones it queued itself
     // and NO slow kernel is launched (saves the ~2 us an almost always empty dependent launch costs per step;
@@ -373,9 +373,11 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             }
             drain = around <= kDrainMaxQueue;
         }
-        const long long quads_per_wave = (((long long)e->P.N + 3) / 4 + 4LL * e->proj_grid - 1) / (4LL * e->proj_grid);
-        if (quads_per_wave * 16 > kDrainListMax) drain = false;        // a workgroup's list must hold every env it steps
         if (e->drain_override >= 0) drain = e->drain_override != 0;
+        // capacity guard, AFTER the override: a workgroup's list must hold every environment it steps (a queued row that found
+        // the list full would not be stepped), so a launch shape that cannot guarantee it always gets the slow kernel
+        const long long quads_per_wave = (((long long)e->P.N + 3) / 4 + 4LL * e->proj_grid - 1) / (4LL * e->proj_grid);
+        if (quads_per_wave * 16 > kDrainListMax) drain = false;
     }
     // With timing on, the two kernels carry their own start / stop events (hipExtLaunchKernel: the
     // events read the dispatch packet's begin / end timestamps, i.e. the duration a kernel trace
@@ -608,7 +610,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(hipMemset(e->d_moer_hist, 0, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS));
     A(hipMemset(e->d_moer_obs, 0, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
     A(hipMemset(e->d_slow_count, 0, 2 * sizeof(int)));
-    A(hipMemset(e->d_tie, 0, 2 * kTieSlots * sizeof(int)));
+    A(hipMemset(e->d_tie, 0, 2 * kTieSlots * sizeof(unsigned long long)));
     A(hipMemset(e->d_slow_list, 0xff, sizeof(int) * N));
     A(copy_h2d(e->d_tables, &T, sizeof(T), e->stream));
     for (auto& ev : e->ev) A(hipEventCreate(&ev));

@@ -79,9 +79,15 @@ public:
         return hipStreamSynchronize(stream);
     }
 
+    // One copier per DEVICE (the calling engine has made its device current): HIP events belong to the device that was
+    // current when they were created and cannot be recorded on another device's stream, so a single process-wide set
+    // would break the second engine of a process that drives two GPUs.  The buffers live until the process ends.
+    static constexpr int kMaxDevices = 64;
     static HostCopier& instance() {
-        static HostCopier c;          // process-wide; the buffers live until the process ends
-        return c;
+        static HostCopier per_device[kMaxDevices];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+        return per_device[dev % kMaxDevices];
     }
 
 private:

@@ -122,7 +122,7 @@ __device__ __forceinline__ bool quad_exact_rows(const Params& P, const LdsNet& n
 __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gid)[kSlots],
                                                const float (&act)[kSlots], const int (&dep)[kSlots],
                                                const double (&rem)[kSlots], double cap,
-                                               double (&y)[kSlots], const bool (&is_cc)[kSlots], int* counters) {
+                                               double (&y)[kSlots], const bool (&is_cc)[kSlots], unsigned long long* counters) {
     // target b and cap h of every slot, once (slots that are compile-time empty fold away)
     double b[kSlots], h[kSlots];
     bool in_g[kSlots];

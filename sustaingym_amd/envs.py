@@ -635,10 +635,11 @@ class MultiAgentEVChargingVectorEnv:
     def __init__(self, data_generators, num_envs: int | None = None, periods_delay: int = 0,
                  moer_forecast_steps: int = 36, project_action_in_env: bool = True,
                  discrete_bins: int = -1, device: int = 0, delay_semantics: str = 'reference',
-                 materialize: bool = False):
+                 materialize: bool = False, charge_calculation: str = 'continuous'):
         assert delay_semantics in ('reference', 'documented')
         self.venv = EVChargingVectorEnv(data_generators, num_envs, moer_forecast_steps,
-                                        project_action_in_env, discrete_bins, device, output='torch')
+                                        project_action_in_env, discrete_bins, device, output='torch',
+                                        charge_calculation=charge_calculation)
         self.num_envs = self.venv.num_envs
         self.possible_agents = self.venv.cn.station_ids[:]
         self.num_agents = len(self.possible_agents)
@@ -695,6 +696,9 @@ class SB3VecEnv(_SB3VecEnvBase):
     def __init__(self, venv: EVChargingVectorEnv):
         assert venv.output == 'numpy'
         self.venv = venv
+        # this adapter copies every array it hands out (SB3's rollout buffer keeps references across steps), so the
+        # vector env underneath may hand out its alternating page-locked buffers instead of copying a first time
+        venv.zero_copy = True
         if _SB3VecEnvBase is not object:       # sets num_envs / spaces, queries get_attr('render_mode')
             super().__init__(venv.num_envs, venv.single_observation_space, venv.single_action_space)
         self.num_envs = venv.num_envs

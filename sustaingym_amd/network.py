@@ -106,9 +106,12 @@ class ChargingNetwork:
         phase = np.asarray(cn._phase_angles, dtype=np.float64).reshape(-1)
         mags = np.asarray(cn.magnitudes, dtype=np.float64).reshape(-1)
         min_pilot = np.asarray(cn.min_pilot_signals, dtype=np.float64).reshape(-1)
-        if not np.isin(min_pilot, (6.0, 8.0)).all():
-            raise ValueError(f'unsupported EVSE types: min_pilot_signals = {sorted(set(min_pilot.tolist()))} '
-                             '(env.py:373 distinguishes 6 A = AeroVironment from 8 A = ClipperCreek only)')
+        # env.py:373-378 tests `min_pilot_signals[i] == 6` and treats EVERY other value as the {0, 8, 16, 24, 32} A EVSE
+        # (an acnportal version may report a FiniteRatesEVSE's minimum as allowable_rates[0] = 0): mirror that, and only
+        # warn about values the reference's rule has never met
+        if not np.isin(min_pilot, (0.0, 6.0, 8.0)).all():
+            warnings.warn(f'min_pilot_signals = {sorted(set(min_pilot.tolist()))}: stations whose value is not 6 A are treated as '
+                          'ClipperCreek {0, 8, 16, 24, 32} A EVSEs, as env.py:373-378 does', stacklevel=2)
         names = [str(c) for c in getattr(cn, 'constraint_index', [f'constraint {i}' for i in range(len(mags))])]
         voltages = np.asarray(getattr(cn, '_voltages', [208.0])).reshape(-1)
         return cls(site, station_ids, A, phase, mags, names, np.where(min_pilot == 6.0, EVSE_AV, EVSE_CC),

@@ -5,12 +5,14 @@ with every seed in turn and steps a ``GreedyAlgorithm`` / ``RandomAlgorithm`` un
 (sustaingym/algorithms/base.py:38-99, algorithms/evcharging/baselines.py:22-51) — is done here the
 other way round: every seed becomes one environment of a batch, the policy lives on the GPU
 (``EVC_ACTION_GREEDY`` / ``EVC_ACTION_RANDOM``) and ``evc_rollout`` plays all 288 periods of all
-episodes without returning to the host.  The result has the columns of the reference's DataFrame
+episodes in ONE kernel launch (csrc/evc_rollout.h: the environments' state stays in registers, no
+per-period action read or observation write).  The result has the columns of the reference's DataFrame
 (``seed``, ``return``, ``max_profit``, ``reward_breakdown``).
 
 MPC / OfflineOptimal (baselines.py:54-223) are cvxpy programs that merely call ``step()``; they stay
-out of scope.  Policies that need Python (a trained network) use
-:class:`~sustaingym_amd.envs.EVChargingVectorEnv` instead.
+out of scope.  Policies that need Python (a trained network, a user's controller) go
+through :func:`run_policy`, which drives any environment of this package — ``EVChargingEnv``, a wrapped
+one, the multi-agent one — through its own ``reset`` / ``step``.
 """
 from __future__ import annotations
 
@@ -83,7 +85,6 @@ class PolicyRollout:
     def run(self, seeds: Iterable[int] | int, env_id_base: int = 0) -> dict[str, np.ndarray | list]:
         """All episodes at once.  Returns ``{'seed', 'return', 'max_profit', 'reward_breakdown',
         'status'}``; ``reward_breakdown`` is a list of dicts like the reference's ``info`` column."""
-        import ctypes as C
         import torch
         seeds = list(range(seeds)) if isinstance(seeds, int) else [int(s) for s in seeds]
         if not seeds:
@@ -97,8 +98,7 @@ class PolicyRollout:
         try:
             eng.upload_moer(moer)
             eng.upload_episodes(ns, sessions, requested, np.arange(B, dtype=np.int32))
-            _lib.check(eng.lib.evc_set_policy_seed(eng.handle, C.c_uint64(self.policy_seed & (2 ** 64 - 1)),
-                                                   int(env_id_base)), 'evc_set_policy_seed')
+            eng.set_policy_seed(self.policy_seed, env_id_base)
             eng.reset()
             out = eng.rollout(policy=self.policy, steps=EPISODE_STEPS, bins=self.bins)
             torch.cuda.synchronize(self.device)
@@ -125,3 +125,30 @@ class PolicyRollout:
 def evaluate(data_generator: AbstractTraceGenerator, policy: str, seeds: Iterable[int] | int, **kwargs):
     """Shorthand: ``PolicyRollout(data_generator, policy, **kwargs).run(seeds)``."""
     return PolicyRollout(data_generator, policy, **kwargs).run(seeds)
+
+
+def run_policy(env, policy, seeds: Iterable[int] | int) -> dict[str, list]:
+    """Evaluation of a host-side policy on ANY single environment of this package through its public API: one
+    episode per seed, ``policy(observation) -> action`` asked once per period.  For callers of the reference's
+    ``BaseAlgorithm.run`` whose controller is Python code (what the device-resident :class:`PolicyRollout` cannot
+    take).  Multi-agent environments (dict-of-agents observations) work too: rewards are summed over agents and an
+    episode ends when every agent is done.  Returns the columns of :meth:`PolicyRollout.run`."""
+    seeds = list(range(seeds)) if isinstance(seeds, int) else [int(s) for s in seeds]
+    out: dict[str, list] = {'seed': [], 'return': [], 'max_profit': [], 'reward_breakdown': []}
+    for seed in seeds:
+        obs, info = env.reset(seed=seed)
+        total, finished = 0.0, False
+        while not finished:
+            obs, reward, terminated, truncated, info = env.step(policy(obs))
+            if isinstance(reward, dict):                                  # PettingZoo-parallel style
+                total += float(sum(reward.values()))
+                finished = all(terminated.values()) or all(truncated.values()) or not terminated
+                info = next(iter(info.values())) if info else {}
+            else:
+                total += float(reward)
+                finished = bool(terminated) or bool(truncated)
+        out['seed'].append(seed)
+        out['return'].append(total)
+        out['max_profit'].append(info.get('max_profit'))
+        out['reward_breakdown'].append(info.get('reward_breakdown'))
+    return out

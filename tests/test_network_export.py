@@ -50,11 +50,22 @@ def test_exported_network_must_keep_the_station_order(tmp_path, monkeypatch):
         site_str_to_site('jpl')
 
 
-def test_unsupported_evse_rejected():
+def test_evse_kind_mirrors_the_reference_rule():
+    """env.py:373-378: `min_pilot_signals[i] == 6` is the AeroVironment EVSE, EVERYTHING else the {0, 8, 16, 24, 32} A one —
+    also a FiniteRatesEVSE reported with min_rate = allowable_rates[0] = 0; unheard-of values only warn."""
+    from sustaingym_amd.network import EVSE_AV, EVSE_CC
     shaped = _AcnportalShaped(caltech_acn())
-    shaped.min_pilot_signals = np.full(54, 0.0)          # BASIC EVSEs: continuous pilots, not env.py:373's rule
-    with pytest.raises(ValueError, match='unsupported EVSE'):
-        ChargingNetwork.from_acnportal(shaped, 'caltech')
+    want = np.asarray(caltech_acn().evse_kind)
+    mp = np.where(want == EVSE_AV, 6.0, 0.0)                   # ClipperCreek reported as 0 A
+    shaped.min_pilot_signals = mp
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        got = ChargingNetwork.from_acnportal(shaped, 'caltech')
+    assert np.array_equal(got.evse_kind, want)
+    shaped.min_pilot_signals = np.where(want == EVSE_AV, 6.0, 5.0)
+    with pytest.warns(UserWarning, match='not 6 A'):
+        got = ChargingNetwork.from_acnportal(shaped, 'caltech')
+    assert np.array_equal(got.evse_kind, want) and (got.evse_kind == EVSE_CC).any()
 
 
 def test_provisional_warning(monkeypatch):

@@ -50,8 +50,36 @@ def main(src: str, dst_prefix: str) -> None:
                 out[f[:-5]] = json.loads(open(p).read().strip().splitlines()[-1])
             except Exception:
                 pass
+    # the code object these figures were measured on (bench.py's roofline.traffic refuses a figure from other kernels)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        from bench import code_object_hash
+        out['code_object_sha256'] = code_object_hash()
+    except Exception as exc:
+        out['code_object_sha256'] = None
+        print('code_object_hash failed:', exc)
     json.dump(out, open(dst_prefix + '_summary.json', 'w'), indent=1)
     print(json.dumps(out['pmc'], indent=1))
+    # proposed profiles/traffic.json: the compact streaming kernel's entry refreshed from this run.  FETCH_SIZE is scaled
+    # by the factor calibrated for this kernel's read shapes (profiles/r2_fetch_calibration.txt: 1.40, against the guide's
+    # 2.0 for 16 B/lane streams); the raw and the x2 figures are kept as bounds.
+    tpath = os.path.join(root, 'profiles', 'traffic.json')
+    cq = [(k, e) for k, e in pmc.items() if 'step_kernel_cquad<true' in k and 'FETCH_SIZE_KB_mean' in e and 'WRITE_SIZE_KB_mean' in e]
+    if cq and os.path.exists(tpath):
+        k, e = max(cq, key=lambda ke: ke[1].get('dispatches_FETCH_SIZE', 0))
+        tj = json.load(open(tpath))
+        f, w = e['FETCH_SIZE_KB_mean'], e['WRITE_SIZE_KB_mean']
+        tj['caltech_N65536_project1_compact'] = {
+            'hbm_bytes_per_launch': int((1.4 * f + w) * 1024), 'fetch_kib': round(f, 1), 'write_kib': round(w, 1),
+            'fetch_factor': 1.4, 'hbm_bytes_per_launch_raw_counters': int((f + w) * 1024),
+            'hbm_bytes_per_launch_guide_x2_rule': int((2 * f + w) * 1024), 'kernel': k,
+            'code_object_sha256': out['code_object_sha256'],
+            'source': f'profiles/{os.path.basename(dst_prefix)}_summary.json (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) x '
+                      'profiles/r2_fetch_calibration.txt (read factor 1.40 for this kernel\'s access shapes instead of the '
+                      'guide\'s 2.0 for 16 B/lane streams)'}
+        json.dump(tj, open(dst_prefix + '_traffic.json', 'w'), indent=1)
+        print('proposed traffic.json ->', dst_prefix + '_traffic.json')
 
 
 if __name__ == '__main__':
