@@ -99,6 +99,11 @@ struct Params {
     // simple rows only are projected in closed form (water-filling) inside the streaming kernel.
     double class_cap[EVC_MAX_GROUPS];
     unsigned simple_rows;                           // bit c set: row c is simple
+    unsigned cap_classes;                           // bit g set: class g carries a cap (class_cap[g] finite)
+    // 1 if every row's magnitude is non-decreasing in every class sum (all pairs of a row's class phasors have a
+    // non-negative inner product): lowering values then never breaks a row that held before — an environment whose
+    // screen left only simple rows open is settled by capping those classes, without evaluating the other rows
+    int monotone_rows;
     double snap_tol;                                // row tolerance after the tie snap: PROJ_TOL + what snapping can add to a row / cap
     unsigned long long* tie_counters;               // [kTieSlots][2] tie_snap_counted (64-bit: a long soak moves > 2^31 values)
     double prox_step;                               // 1 / (Gershgorin bound on lambda_max(B B')): step of the solver's proximal-gradient safeguard

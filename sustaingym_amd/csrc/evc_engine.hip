@@ -58,7 +58,7 @@ constexpr int kQlenRing = 288;           // one report per period of a day
 #define EVC_PROJ_WAVES 3                // wavefronts per SIMD the PROJECTING lean compact kernels are held to (evc_cquad.h, WAVES)
 #endif
 constexpr int kDrainLookBack = 12, kDrainLookAhead = 36;   // periods of the day around the current one whose reports decide the step's mode
-constexpr int kDrainMaxQueue = 16;      // in-kernel drain only while NO step of the last day queued more than this
+constexpr int kDrainMaxQueueDefault = 16;   // in-kernel drain only while NO step of the last day queued more than this (EVC_DRAIN_MAXQ overrides)
 
 struct evc_engine {
     int device = 0;
@@ -93,6 +93,7 @@ struct evc_engine {
     unsigned long long step_index = 0;
     bool warmed = false;          // both lean streaming copies have been launched once
     int drain_override = -1;      // EVC_DRAIN=0/1 forces a mode (measurements)
+    int drain_max_queue = kDrainMaxQueueDefault;
     int* d_idbuf = nullptr;       // reset ids/slots staging [2N]
     double* d_metrics = nullptr;  // [8]
     double* d_maxprofit = nullptr;  // [bank_slots] env.py:422-429 of the episode in each slot
@@ -258,6 +259,17 @@ int build_tables(const evc_network_desc* net, Params& P, NetTables& T) {
             if (cap < P.class_cap[cls]) P.class_cap[cls] = cap;
         }
     }
+    P.cap_classes = 0u;
+    for (int g = 0; g < P.G; g++)
+        if (P.class_cap[g] < HUGE_VAL) P.cap_classes |= 1u << g;
+    // monotone rows: |sum_g M_c[g] S_g|^2 = sum_gh Re(M_c[g] conj M_c[h]) S_g S_h does not decrease in any S_g >= 0 if no
+    // pair of the row's class phasors has a negative inner product
+    P.monotone_rows = 1;
+    for (int c = 0; c < m; c++)
+        for (int g = 0; g < P.G; g++)
+            for (int h = g + 1; h < P.G; h++)
+                if (T.Mre[g][c] * T.Mre[h][c] + T.Mim[g][c] * T.Mim[h][c] < -1e-12) P.monotone_rows = 0;
+    if (const char* s = getenv("EVC_CAPS_SHORTCUT")) P.monotone_rows = P.monotone_rows && atoi(s) != 0;   // measurements: 0 disables the shortcut
     return EVC_OK;
 }
 
@@ -351,7 +363,15 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     const bool dbg = out->pilots || out->rates || out->projected || out->returns ||
                      action_kind == EVC_ACTION_GREEDY;
     // drain mode (see evc_engine): the lean compact streaming kernel can drain short queues itself
+    // Who finishes the rows whose projection needs the iterative solver (lean compact streaming kernel):
+    //   1  the workgroup that queued them, from a list of its own once its streaming work is done (all four wavefronts);
+    //   0  the slow kernel (a second launch) from the global queue — also every other kernel family.
+    // Default: by the time of day, from the queue lengths the kernels report (below); EVC_DRAIN=0|1 forces a mode.
+    // Measured in round 3 and rejected: solving a row where it stands inside the period's body, and
+    // solving between two quads of the wavefront that queued it — the call's live ranges cost the streaming path 1.4 - 4 us
+    // per step and the launch still ends with the last solve's full latency.
     bool drain = false;
+    int mode = 0;
     if (e->P.project && e->use_quad && e->compact && !dbg && e->h_qlen) {
         // longest queue among the last day's reports; slots no kernel has written yet hold INT_MAX, so an engine
         // starts with the slow kernel and only drops it after a whole day of short queues (the host runs ahead of
@@ -359,7 +379,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         // queues ramp up within a few periods — 107 instead of 78 us per step on JPL's GMM days, measured)
         int recent = 0;
         for (int i = 0; i < kQlenRing; i++) { const int v = ((volatile int*)e->h_qlen)[i]; if (v > recent) recent = v; }
-        drain = recent <= kDrainMaxQueue;
+        drain = recent <= e->drain_max_queue;
         if (!drain && recent != INT_MAX) {
             // A day with a congested part.  The ring is indexed by the period of the day, so the slots around this step's hold
             // the last reports for this time of day — today's behind it (as far as the GPU has come), yesterday's ahead.
@@ -371,13 +391,14 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 const int v = ((volatile int*)e->h_qlen)[(here + d + kQlenRing) % kQlenRing];
                 if (v > around) around = v;
             }
-            drain = around <= kDrainMaxQueue;
+            drain = around <= e->drain_max_queue;
         }
         if (e->drain_override >= 0) drain = e->drain_override != 0;
         // capacity guard, AFTER the override: a workgroup's list must hold every environment it steps (a queued row that found
         // the list full would not be stepped), so a launch shape that cannot guarantee it always gets the slow kernel
         const long long quads_per_wave = (((long long)e->P.N + 3) / 4 + 4LL * e->proj_grid - 1) / (4LL * e->proj_grid);
         if (quads_per_wave * 16 > kDrainListMax) drain = false;
+        mode = drain ? 1 : 0;
     }
     // With timing on, the two kernels carry their own start / stop events (hipExtLaunchKernel: the
     // events read the dispatch packet's begin / end timestamps, i.e. the duration a kernel trace
@@ -394,8 +415,8 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     case W:                                                                                        \
         if (e->P.project) {                                                                        \
             if (!dbg && !e->warmed && e->use_quad && e->compact) {                                 \
-                /* first lean step: run BOTH copies once on zero environments, so that neither's first  \
-                   launch (code load, scratch sizing: milliseconds) lands in a later mode switch */      \
+                /* first lean step: run the copies this engine may use once on zero environments, so that none's \
+                   first launch (code load, scratch sizing: milliseconds) lands in a later mode switch */      \
                 Params pw = e->P;                                                                  \
                 pw.N = 0;                                                                          \
                 pw.host_qlen = nullptr;                                                            \
@@ -404,9 +425,9 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 e->warmed = true;                                                                  \
             }                                                                                      \
             if (dbg) launch(KDBG, GRID, 256, 0);                                                   \
-            else if (drain) launch(KDRAIN, LEANGRID, 256, 0);                                      \
+            else if (mode == 1) launch(KDRAIN, LEANGRID, 256, 0);                                  \
             else launch(KFAST, LEANGRID, 256, 0);                                                  \
-            if (!drain) {                                                                          \
+            if (mode == 0) {                                                                       \
                 launch(solver_step_kernel<W>, e->solver_grid, 256, 1);                              \
                 solver_ran = true;                                                                 \
             }                                                                                      \
@@ -419,8 +440,8 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 (step_kernel_quad<true, W, false>),                                                \
                 (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, e->quad_grid, W)
 #define EVC_LAUNCH_CQUAD(W)                                                                         \
-    EVC_LAUNCH_((step_kernel_cquad<true, W, true>), (step_kernel_cquad<true, W, false, false, EVC_PROJ_WAVES>), \
-                (step_kernel_cquad<true, W, false, true, EVC_PROJ_WAVES>),                          \
+    EVC_LAUNCH_((step_kernel_cquad<true, W, true>), (step_kernel_cquad<true, W, false, 0, EVC_PROJ_WAVES>), \
+                (step_kernel_cquad<true, W, false, 1, EVC_PROJ_WAVES>),                             \
                 (dbg ? step_kernel_cquad<false, W, true> : step_kernel_cquad<false, W, false>), e->quad_grid, e->proj_grid, W)
 #define EVC_LAUNCH_WAVE(W)                                                                          \
     EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, e->step_grid, W)
@@ -660,7 +681,9 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     } else {
         e->h_qlen = nullptr;
     }
-    if (const char* s = getenv("EVC_DRAIN")) e->drain_override = atoi(s) != 0 ? 1 : 0;
+    if (const char* s = getenv("EVC_DRAIN"))
+        if (*s && strcmp(s, "auto") != 0) e->drain_override = atoi(s) != 0 ? 1 : 0;
+    if (const char* s = getenv("EVC_DRAIN_MAXQ")) e->drain_max_queue = atoi(s);
     *out = e;
     return EVC_OK;
 }
@@ -1145,6 +1168,19 @@ int evc_last_slow_count(evc_engine* e, int32_t* count) {
     *count = both[(e->step_parity + 1) & 1];
     return EVC_OK;
 }
+
+#ifdef EVC_WG_TIMING
+int evc_debug_read_tie(evc_engine* e, unsigned long long* out /* [512] */, int clear) {
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return -4;
+    if (copy_d2h(out, e->d_tie, sizeof(unsigned long long) * 2 * kTieSlots, e->stream) != hipSuccess) return -4;
+    if (clear && hipMemset(e->d_tie, 0, sizeof(unsigned long long) * 2 * kTieSlots) != hipSuccess) return -4;
+    return 0;
+}
+int evc_debug_read_slow_list(evc_engine* e, int* out, int count) {
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return -4;
+    return copy_d2h(out, e->d_slow_list, sizeof(int) * (size_t)count, e->stream) == hipSuccess ? 0 : -4;
+}
+#endif
 
 #ifdef EVC_SOLVER_STATS
 int evc_debug_solver_stats(unsigned long long* out8 /* [16] */) {

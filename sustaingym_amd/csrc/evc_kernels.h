@@ -44,6 +44,23 @@ __device__ __forceinline__ void stage_net(LdsNet& s, const Params& P) {
     __syncthreads();
 }
 
+// What the rarely taken projection branch of the streaming kernels needs of Params, held in LDS (stage_rare): read from
+// the kernel-argument segment there, every field is a scalar load that misses the scalar cache — measured on the
+// benchmark's day, 190 visits per step of ~5 us each, most of it such round trips, and the launch ends with the last visit.
+struct LdsRare {
+    double class_cap[EVC_MAX_GROUPS];
+    double snap_tol;
+    unsigned simple_rows, cap_classes;
+    int monotone_rows, G;
+};
+__device__ __forceinline__ void stage_rare(LdsRare& r, const Params& P) {          // before a workgroup barrier
+    if (threadIdx.x < EVC_MAX_GROUPS) r.class_cap[threadIdx.x] = P.class_cap[threadIdx.x];
+    if (threadIdx.x == 0) {
+        r.snap_tol = P.snap_tol; r.simple_rows = P.simple_rows; r.cap_classes = P.cap_classes;
+        r.monotone_rows = P.monotone_rows; r.G = P.G;
+    }
+}
+
 // Per-lane constants of the network (computed once per wave).
 struct LaneNet {
     int gid;          // station class of this lane, -1 outside the network

@@ -90,12 +90,15 @@ __device__ __forceinline__ double row_allreduce_min_f64(double v) {
 
 // Exact float64 constraint rows of schedule y for the rows flagged `want` (row-uniform): returns,
 // for lane q < m, whether constraint row q is violated; cap_viol = classes above their cap.
-__device__ __forceinline__ bool quad_exact_rows(const Params& P, const LdsNet& net, unsigned q, unsigned m,
+// G / class_cap: the class count and the class caps (Params::class_cap), passed as they are held by the caller — the
+// streaming kernels keep a copy in LDS: in a rarely taken branch every `P.` field is a scalar load from the kernel-argument
+// segment that misses the scalar cache, one dependent round trip per loop iteration.
+__device__ __forceinline__ bool quad_exact_rows(int G, const double* class_cap, const LdsNet& net, unsigned q, unsigned m,
                                                 const int (&st_gid)[kSlots], const double (&y)[kSlots],
                                                 bool want, unsigned& cap_viol, double tol = Consts::PROJ_TOL) {
     double re = 0.0, im = 0.0;
     cap_viol = 0u;
-    for (int g0 = 0; g0 < P.G; g0 += 4) {          // four independent reduction ladders in flight (a lone one is all latency)
+    for (int g0 = 0; g0 < G; g0 += 4) {            // four independent reduction ladders in flight (a lone one is all latency)
         double S[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -107,9 +110,9 @@ __device__ __forceinline__ bool quad_exact_rows(const Params& P, const LdsNet& n
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int g = g0 + u;
-            if (g < P.G) {
+            if (g < G) {
                 if (q < m) { re += net.Mre[g][q] * S[u]; im += net.Mim[g][q] * S[u]; }
-                if (S[u] > P.class_cap[g] * (1.0 + tol)) cap_viol |= 1u << g;
+                if (S[u] > class_cap[g] * (1.0 + tol)) cap_viol |= 1u << g;
             }
         }
     }
@@ -122,7 +125,8 @@ __device__ __forceinline__ bool quad_exact_rows(const Params& P, const LdsNet& n
 __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gid)[kSlots],
                                                const float (&act)[kSlots], const int (&dep)[kSlots],
                                                const double (&rem)[kSlots], double cap,
-                                               double (&y)[kSlots], const bool (&is_cc)[kSlots], unsigned long long* counters) {
+                                               double (&y)[kSlots], const bool (&is_cc)[kSlots], unsigned long long* counters,
+                                               unsigned long long* pass_count = nullptr) {
     // target b and cap h of every slot, once (slots that are compile-time empty fold away)
     double b[kSlots], h[kSlots];
     bool in_g[kSlots];
@@ -135,6 +139,7 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
     double nu = 0.0, lo = 0.0, hi = 64.0;
     bool run = on;
     for (int it = 0; it < 80 && __ballot(run) != 0ull; it++) {
+        if (pass_count) *pass_count += 1ull;
         double part = 0.0, nextbp = 1e300;
         unsigned nfree = 0u;
 #pragma unroll
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
                 // (pod breaker) violations are projected in closed form by water-filling inside the
                 // row; anything else is queued for the slow kernel.
                 unsigned cap_viol;
-                bool hard = quad_exact_rows(P, net, q, m, st_gid, y, undecided, cap_viol);
+                bool hard = quad_exact_rows(P.G, P.class_cap, net, q, m, st_gid, y, undecided, cap_viol);
                 bool anyviol = row_any(hard, row);
                 // Class caps are filled whenever one is violated, also beside violated multi-class rows:
                 // if the point projected onto box and caps satisfies every row it is the projection
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
                     }
                     unsigned cv2;
                     // re-verify every row on the snapped values: Params::snap_tol = PROJ_TOL + the most the snap can add to a row
-                    const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, P.snap_tol), row);
+                    const bool still = row_any(quad_exact_rows(P.G, P.class_cap, net, q, m, st_gid, y, fill, cv2, P.snap_tol), row);
                     anyviol = anyviol && !(fill && !still);
                 }
                 const bool queue_me = undecided && anyviol;       // cones (or unsettled): slow kernel

@@ -45,6 +45,7 @@ struct RolloutLds {
     uint4 st_mulw[64];
     uint4 st_mulw_hi[64];
     unsigned char st_info[64];
+    LdsRare rare;                                  // Params fields of the rarely taken projection branch
     int noconv[4];                                 // per wavefront: bit r = the solve of row r did not converge
 };
 
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256, EVC_ROLLOUT_WAVES) void rollout_kernel(Params 
     if (tid < 4u) S.noconv[tid] = 0;
 #pragma unroll
     for (int j = 0; j < kSlots; j++) S.img[wv][row][j * 16 + q].h_or_y = 0.0;
+    stage_rare(S.rare, P);
     stage_net(net, P);                              // ends with the workgroup barrier
 
     const unsigned nquads = (N + 3u) >> 2;
@@ -301,20 +303,42 @@ __global__ __launch_bounds__(256, EVC_ROLLOUT_WAVES) void rollout_kernel(Params 
 #pragma unroll
                 for (int c = 0; c < kSlots; c++) st_gid[c] = valid[c] ? (int)(st_info[st[c]] & 0x7fu) : -1;
                 unsigned cap_viol;
-                const bool hard = quad_exact_rows(P, net, q, m, st_gid, y, undecided, cap_viol);
-                bool anyviol = row_any(hard, row);
+                bool anyviol;
+                // only class caps left open by the screen on a network with monotone rows: cap those classes, nothing else
+                // to evaluate (evc_cquad.h, "Shortcut")
+                const unsigned open_rows = (unsigned)(__ballot(maybe) >> (row * 16u)) & 0xffffu;
+                const bool caps_only = S.rare.monotone_rows != 0 && (open_rows & ~S.rare.simple_rows) == 0u;
+                const bool shortcut = __ballot(undecided && !caps_only) == 0ull;
+                if (shortcut) {
+                    cap_viol = 0u;
+                    const int G_ = S.rare.G;
+                    const unsigned capped = S.rare.cap_classes;
+                    for (int g = 0; g < G_; g++) {
+                        if (!((capped >> g) & 1u)) continue;
+                        double part = 0.0;
+#pragma unroll
+                        for (int c = 0; c < kSlots; c++) part += (st_gid[c] == g) ? y[c] : 0.0;
+                        if (row_allreduce_f64(part) > S.rare.class_cap[g] * (1.0 + Consts::PROJ_TOL)) cap_viol |= 1u << g;
+                    }
+                    anyviol = false;
+                } else {
+                    const bool hard = quad_exact_rows(S.rare.G, S.rare.class_cap, net, q, m, st_gid, y, undecided, cap_viol);
+                    anyviol = row_any(hard, row);
+                }
                 const bool fill = undecided && cap_viol != 0u;
                 if (__builtin_expect(__ballot(fill) != 0ull, 0)) {
                     bool slot_cc[kSlots];
 #pragma unroll
                     for (int c = 0; c < kSlots; c++) slot_cc[c] = valid[c] && (st_info[st[c]] >> 7) != 0u;
-                    for (int g = 0; g < P.G; g++) {
+                    for (int g = 0; g < S.rare.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
-                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, nullptr);
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, S.rare.class_cap[g], y, slot_cc, nullptr);
                     }
-                    unsigned cv2;
-                    const bool still = row_any(quad_exact_rows(P, net, q, m, st_gid, y, fill, cv2, P.snap_tol), row);
-                    anyviol = anyviol && !(fill && !still);
+                    if (!shortcut) {
+                        unsigned cv2;
+                        const bool still = row_any(quad_exact_rows(S.rare.G, S.rare.class_cap, net, q, m, st_gid, y, fill, cv2, S.rare.snap_tol), row);
+                        anyviol = anyviol && !(fill && !still);
+                    }
                 }
                 const bool solve_me = undecided && anyviol;       // cone rows bind (or unsettled): iterative solver
                 const unsigned long long solve_mask = __ballot(solve_me);
