@@ -618,6 +618,17 @@ def secondary_battery(dev_index) -> dict:
     torch.cuda.synchronize(dev)
     wall = (time.perf_counter() - t0) / 200 * 1e3
     gpu = e0.elapsed_time(e1) / 200
+    # the floor of ANY back-to-back kernel launch from this process, measured the same way: a one-element torch kernel
+    one = torch.zeros(1, device=dev)
+    for _ in range(32):
+        one.add_(1.0)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(200):
+        one.add_(1.0)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    empty = e0.elapsed_time(e1) / 200
     alg = (4 * k + 6) * 4 + 2 * k * 4 + 8 + 1 + 2 * 16          # obs row + bids + reward + done + state r/w
     env.close()
     return {'workload': f'{N} battery-dispatch envs (synthetic price-taker step), k={k}',
@@ -625,7 +636,8 @@ def secondary_battery(dev_index) -> dict:
             'roofline': {'bound': 'hbm', 'kernel': 'bat::step_kernel', 'algorithmic_bytes_per_env_step': alg,
                          'achieved': round(alg * N / (gpu * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(alg * N / (gpu * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         'note': 'launch-latency bound at this size (940 B x 16 384 = 15 MB per launch)'}}
+                         'note': 'launch-latency bound at this size (940 B x 16 384 = 15 MB per launch): compare empty_launch_ms'},
+            'empty_launch_ms': round(empty, 5), 'over_empty_launch': round(gpu / empty, 2)}
 
 
 def main():

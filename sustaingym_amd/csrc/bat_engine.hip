@@ -76,24 +76,62 @@ __global__ __launch_bounds__(256) void bat_reset_kernel(BatParams P, const int* 
     // forecasts in the first observation start at index 1 like every later one (lhat[t+1 .. t+k])
 }
 
-__global__ __launch_bounds__(256) void bat_step_kernel(BatParams P, const float* bids, float* obs, double* reward,
-                                                       unsigned char* terminated) {
-    const int lane = threadIdx.x & 63;
-    const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
+// One step.  Round 3 form: FOUR environments per wavefront (a 16-lane row each), so a 256-thread workgroup steps 16 and a
+// launch of 16 384 environments is 1 024 workgroups instead of 4 096; and two dependent memory levels instead of three:
+// everything that does not depend on (t, slot) — state, the two bids that decide, the bid row the observation copies — is
+// requested at once, then the traces at (slot, t).  The round-2 kernel (one wavefront per environment, t -> slot -> trace
+// behind an early-exit branch) ran 14.5 us for 15 MB.
+__global__ __launch_bounds__(256) void bat_step_kernel(BatParams P, const float* __restrict__ bids, float* __restrict__ obs,
+                                                       double* __restrict__ reward, unsigned char* __restrict__ terminated) {
+    const int q = threadIdx.x & 15;
+    const int env = (blockIdx.x * 256 + threadIdx.x) >> 4;
     if (env >= P.N) return;
+    const int k = P.k, F = P.F;
+    // level 1 (no dependencies)
     const int t = P.t[env];
-    if (t >= BAT_EPISODE_STEPS) {                       // step after termination: no-op, reward 0
-        if (lane == 0) { reward[env] = 0.0; terminated[env] = 1; }
-        return;
-    }
     const int slot = P.slot[env];
     const double e = P.energy[env];
-    const float* a = bids + (size_t)env * 2 * P.k;
-    const double bid_c = (double)a[0], bid_d = (double)a[P.k];
+    const double ret_in = P.ret[env];
+    const float* a = bids + (size_t)env * 2 * k;
+    const float bc = a[0], bd = a[k];
+    // The observation row as 8-byte PAIRS (F = 4k + 6 is even, rows are 8-byte aligned): pair 0 = (t, e), pairs 1..k = the bid
+    // row, pair k+1 = (x, p), then (l, lhat..., m, mhat...) wherever the pair boundaries fall.  Lane q of the row owns pairs q, q + 16, ...:
+    // half the store instructions of a float-per-lane copy.
+    constexpr int kPairPasses = (4 * BAT_MAX_FORECAST + 6 + 31) / 32;
+    float2 acopy[kPairPasses];
+#pragma unroll
+    for (int j = 0; j < kPairPasses; j++) {
+        const int pr = q + 16 * j;                                  // pair index
+        acopy[j] = (pr >= 1 && pr <= k) ? *reinterpret_cast<const float2*>(a + 2 * (pr - 1)) : make_float2(0.0f, 0.0f);
+    }
+    float* row = obs + (size_t)env * F;
+    if (t >= BAT_EPISODE_STEPS) {                       // step after termination: no-op, reward 0
+        if (q == 0) { reward[env] = 0.0; terminated[env] = 1; }
+        return;
+    }
+    // level 2 (needs t, slot)
     const size_t tr = (size_t)slot * BAT_TRACE_LEN + t;
     const float pf = P.price[tr], lf = P.load[tr], mf = P.moer[tr];
+    const float* lfc = P.load_fc + (size_t)slot * (BAT_TRACE_LEN + k) + t + 2;      // lhat of the NEXT observation: t1 + 1 + j
+    const float* mfc = P.moer_fc + (size_t)slot * (BAT_TRACE_LEN + k) + t + 2;
+    // forecast floats of the pairs: sources are only 4-byte aligned (they start at t + 2): one float load per element
+    float2 fcopy[kPairPasses];
+    auto forecast = [&](int i) -> float {                           // output float i, if it is a forecast
+        if (i >= 5 + 2 * k && i < 5 + 3 * k) return lfc[i - (5 + 2 * k)];
+        if (i >= 6 + 3 * k && i < 6 + 4 * k) return mfc[i - (6 + 3 * k)];
+        return 0.0f;
+    };
+#pragma unroll
+    for (int j = 0; j < kPairPasses; j++) {
+        const int pr = q + 16 * j;
+        fcopy[j] = make_float2(forecast(2 * pr), forecast(2 * pr + 1));
+    }
+    const int t1 = t + 1;
+    const bool done = t1 >= BAT_EPISODE_STEPS;
+    const double term_price = done ? P.terminal_price[slot] : 0.0;
+
     const double p = (double)pf, m = (double)mf;
-    const bool sell = p >= bid_d, buy = p <= bid_c;
+    const bool sell = p >= (double)bd, buy = p <= (double)bc;
     double x = 0.0, e1 = e;
     if (sell && !buy) {
         x = fmin(P.step_mwh, P.eta_d * e);
@@ -103,15 +141,32 @@ __global__ __launch_bounds__(256) void bat_step_kernel(BatParams P, const float*
         e1 = e - P.eta_c * x;
     }
     e1 = fmin(fmax(e1, 0.0), P.cap);
-    const int t1 = t + 1;
-    const bool done = t1 >= BAT_EPISODE_STEPS;
     double r = p * x + P.pco2 * m * x;
-    if (done) r -= P.terminal_price[slot] * fmax(0.0, P.e0 - e1);
-    write_obs(P, obs + (size_t)env * P.F, lane, t1, e1, slot, a, (float)x, pf, lf, mf);
-    if (lane == 0) {
+    if (done) r -= term_price * fmax(0.0, P.e0 - e1);
+
+    // observation [t, e, a(2k), x, p, l, lhat(k), m, mhat(k)]
+    float2* row2 = reinterpret_cast<float2*>(row);
+    auto scalar = [&](int i, float v) -> float {                    // output float i, if it is one of the six scalars
+        if (i == 0) return (float)t1;
+        if (i == 1) return (float)e1;
+        if (i == 2 + 2 * k) return (float)x;
+        if (i == 3 + 2 * k) return pf;
+        if (i == 4 + 2 * k) return lf;
+        if (i == 5 + 3 * k) return mf;
+        return v;
+    };
+#pragma unroll
+    for (int j = 0; j < kPairPasses; j++) {
+        const int pr = q + 16 * j;
+        float2 v = (pr >= 1 && pr <= k) ? acopy[j] : fcopy[j];
+        v.x = scalar(2 * pr, v.x);
+        v.y = scalar(2 * pr + 1, v.y);
+        if (pr < F / 2) row2[pr] = v;
+    }
+    if (q == 0) {
         P.energy[env] = e1;
         P.t[env] = t1;
-        P.ret[env] += r;
+        P.ret[env] = ret_in + r;
         reward[env] = r;
         terminated[env] = done ? 1 : 0;
     }
@@ -226,7 +281,7 @@ int bat_reset(bat_engine* e, const int32_t* slots, float* obs_dev) {
 int bat_step(bat_engine* e, const float* bids_dev, float* obs_dev, double* reward_dev, uint8_t* terminated_dev) {
     if (!e || !bids_dev || !obs_dev || !reward_dev || !terminated_dev) return fail(-1, "bat_step: null argument");
     HIP_TRY(hipSetDevice(e->device));
-    hipLaunchKernelGGL(bat_step_kernel, dim3((e->P.N + 3) / 4), dim3(256), 0, e->stream, e->P, bids_dev, obs_dev,
+    hipLaunchKernelGGL(bat_step_kernel, dim3((e->P.N + 15) / 16), dim3(256), 0, e->stream, e->P, bids_dev, obs_dev,
                        reward_dev, terminated_dev);
     HIP_TRY(hipGetLastError());
     e->env_steps += (unsigned long long)e->P.N;
