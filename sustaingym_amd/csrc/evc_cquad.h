@@ -37,31 +37,25 @@ struct alignas(16) StationCell {
 // streaming work is done, the same memory serves as the slow path's SolverLds = {LdsNet net; workspace}
 // (in-kernel queue drain, DRAIN = true).
 constexpr int kDrainListMax = 256;
-// One wavefront's per-step images: [row][station] cells the entries scatter into and the station lanes read back
-// (observation fields + delivered amps, summed in station order: the result does not depend on the entry order, i.e. not
-// on the history of plug-ins, and equals the station-layout kernels' bit for bit; zero between steps) and the clamped
-// actions of the step.  Between two quads the images are idle, and a wavefront's 5 KB hold one solver workspace: the
-// in-kernel slow path (DRAIN = 1, 2) works on this memory and clears it again.
-struct WaveImages {
-    StationCell obs[4][64];
-    float act[4][64];
-};
-static_assert(sizeof(SolverWs) <= sizeof(WaveImages), "a solver workspace must fit a wavefront's per-step images");
 struct CquadLds {
     LdsNet net;
-    union PerWave {
-        WaveImages img;
-        SolverWs ws;
-    } wave[4];
+    union Images {
+        struct {
+            // [wave][row][station] image the entries scatter into and the station lanes read back: observation
+            // fields + delivered amps (summed in station order: the result does not depend on the entry order,
+            // i.e. not on the history of plug-ins, and equals the station-layout kernels' bit for bit); zero
+            // between steps
+            StationCell obs_img[4][4][64];
+            float act_img[4][4][64];    // [wave][row][station] clamped action of this step
+        } s;
+        SolverWs solver_workspace;
+    } u;
     uint4 st_mulw[64];          // per station: 0 / 1 / 65536 multipliers of packed words 0..3
     uint4 st_mulw_hi[64];       // words 4..7
     unsigned char st_info[64];  // class id | ClipperCreek << 7
-    LdsRare rare;               // Params fields of the rarely taken projection branch
     int next_quad;              // next of the workgroup's quads nobody has taken yet (see the loop over quads)
-    int drain_slot;             // DRAIN = 1: workspace ticket of the draining wavefronts
-    int drain_next;             // DRAIN = 1: next list entry nobody has taken yet
-    int local_count;            // DRAIN = 1: environments this workgroup queued for its own slow path ...
-    int local_list[kDrainListMax];   // ... (the engine enables DRAIN = 1 only while a workgroup steps at most that many environments)
+    int local_count;            // DRAIN: environments this workgroup queued for its own slow path ...
+    int local_list[kDrainListMax];   // ... (the engine enables DRAIN only while a workgroup steps at most that many environments)
 };
 
 // The in-kernel drain behind a real call (DRAIN kernels): inlined, the slow path's code and live ranges cost
@@ -80,22 +74,11 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
     const StepIO& io = *(const StepIO*)(ka + kStepIOKernargOffset);
     typedef __attribute__((address_space(3))) CquadLds LdsImage;
     CquadLds& S = *(CquadLds*)(LdsImage*)(size_t)(unsigned)rfl((int)lds);
-    const int lane = (int)__lane_id();            // lane = station, without asking the caller for work-item ids
+    const int lane = (int)__lane_id();            // wave 0 of the workgroup: lane = thread id, without asking the caller for it
     const int count = rfl(S.local_count < kDrainListMax ? S.local_count : kDrainListMax);
-    // Every wavefront of the workgroup drains (round 3; round 2: wavefront 0 alone, which serialised a congested
-    // step's queue): a ticket gives it one of the four workspaces that replace the per-step images (CquadLds::Images),
-    // then it takes list entries one at a time — a long solve on one wavefront does not hold the others back.
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(&S.drain_slot, 1);
-    slot = rfl(slot) & 3;
-    SolverLds L(S.net, S.wave[slot].ws);
-    for (;;) {
-        int i = 0;
-        if (lane == 0) i = atomicAdd(&S.drain_next, 1);
-        i = rfl(i);
-        if (i >= count) break;
-        solve_env<WORDS>(P, io, L, lane, rfl(S.local_list[i]), slot);
-    }
+    // the slow path works on the workgroup's tables and on the memory of the per-step images (CquadLds::Images)
+    SolverLds L(S.net, S.u.solver_workspace);
+    for (int i = 0; i < count; i++) solve_env<WORDS>(P, io, L, lane, rfl(S.local_list[i]));
 }
 
 // DRAIN: no slow kernel is launched after this one.  Each workgroup keeps the environments whose projection
@@ -113,28 +96,22 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
 // interleaved A/B) and 4 is 1.2 us faster without; on congested days, where most wavefronts run a wide copy, 3 wins:
 // Caltech's GMM day 42.1 -> 38.8 us per step, JPL's streaming kernel 45.2 -> 34.6 (38.3 at 2).  The engine launches the
 // projecting lean kernels at 3 (EVC_PROJ_WAVES, evc_engine.hip), everything else at EVC_CQUAD_WAVES.
-template <bool PROJECT, int WORDS, bool DBG, int DRAIN = 0, int WAVES = EVC_CQUAD_WAVES>
+template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES>
 __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params P, StepIO io) {
-    static_assert(DRAIN == 0 || (DRAIN == 1 && PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");
+    static_assert(!DRAIN || (PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");
     __shared__ CquadLds S;
     __shared__ double dbg_img[DBG ? 4 : 1][4][64];     // unused (and dropped) in the lean kernels
     LdsNet& net = S.net;
     auto& st_mulw = S.st_mulw;
     auto& st_mulw_hi = S.st_mulw_hi;
     auto& st_info = S.st_info;
+    auto& obs_img = S.u.s.obs_img;
+    auto& act_img = S.u.s.act_img;
 
     const unsigned tid = threadIdx.x, lane = tid & 63u, q = lane & 15u, row = lane >> 4, wv = tid >> 6;
     const unsigned n = (unsigned)P.n, F = (unsigned)P.F;
     const unsigned m = (unsigned)P.m, k = (unsigned)P.k;
     const unsigned N = (unsigned)P.N;
-#ifdef EVC_WG_TIMING               /* diagnostic builds only: per-wavefront time stamps (100 MHz) into the slow list's memory */
-    unsigned long long* const wg_stamp = (unsigned long long*)P.slow_list + ((size_t)blockIdx.x * 4u + wv) * 8u;
-    unsigned long long rare_sum = 0ull, rare_cnt = 0ull, rare_max = 0ull, rare_sum2 = 0ull;
-    if (lane == 0u && !DBG && P.N > 0) wg_stamp[0] = wall_clock64();
-#define EVC_STAMP(i) do { if (lane == 0u && !DBG && P.N > 0) wg_stamp[i] = wall_clock64(); } while (0)
-#else
-#define EVC_STAMP(i) do { } while (0)
-#endif
 
     // dense side: station j*16+q of the row (action range check, observation stores)
     bool st_valid[kSlots];
@@ -201,8 +178,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     if (tid == 0u) S.next_quad = 4;
     if (DRAIN && tid == 0u) {
         S.local_count = 0;
-        S.drain_slot = 0;
-        S.drain_next = 0;
         // the other control block still holds the PREVIOUS step's total (its launch is complete): report it to
         // the host (drain mode decision) and clear it for the next step
         if (blockIdx.x == 0u) queue_begin_drain(P, P.slow_count_next[0]);
@@ -222,16 +197,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     }
 #pragma unroll
     for (int j = 0; j < kSlots; j++) {
-        S.wave[wv].img.obs[row][j * 16 + q] = StationCell{0.0f, 0.0f, 0.0};
-        S.wave[wv].img.act[row][j * 16 + q] = 0.0f;
+        obs_img[wv][row][j * 16 + q] = StationCell{0.0f, 0.0f, 0.0};
+        act_img[wv][row][j * 16 + q] = 0.0f;
         if (DBG) dbg_img[wv][row][j * 16 + q] = 0.0;
     }
-    stage_rare(S.rare, P);
     stage_net(net, P);                              // ends with the workgroup barrier
-    EVC_STAMP(1);
 
-    StationCell* const obs_row = S.wave[wv].img.obs[row];
-    float* const act_row = S.wave[wv].img.act[row];
+    StationCell* const obs_row = obs_img[wv][row];
+    float* const act_row = act_img[wv][row];
     double* const dbg_row = dbg_img[DBG ? wv : 0][row];
 
     auto station_mulw = [&](unsigned st, unsigned (&mw)[WORDS]) {
@@ -358,11 +331,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                 maybe = !(mag2 < net.thr_y2[q]);
                 maybe_p = !(mag2 < net.thr_yp2[q]);
             }
-#ifdef EVC_WARM_RARE           /* experiment: one wavefront per workgroup takes the exact-rows branch in its first quad (same results) */
-            bool undecided = live && (row_any(maybe, row) || (wv == 1u && quad == walk.first));
-#else
             bool undecided = live && row_any(maybe, row);
-#endif
             pilots_screened = !row_any(maybe_p, row);
 #ifdef EVC_COUNT_UNDECIDED         /* diagnostic builds only: environments the screen leaves undecided, in metrics[7] */
             if (undecided && q == 0u) atomicAdd(P.tie_counters + 2 * (env & (kTieSlots - 1)) + 1, 1ull);
@@ -371,59 +340,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             undecided = false;
 #endif
             if (__builtin_expect(__ballot(undecided) != 0ull, 0)) {
-#ifdef EVC_WG_TIMING
-                const unsigned long long t_rare = wall_clock64();
-#endif
-#ifndef EVC_NO_RARE_PRIO
-                // The launch ends with the wavefront that met this branch in its last quad (190 visits per step on
-                // the benchmark's day, chains of dependent float64 ladders and a divide per Newton pass): while it is in here it
-                // gets the SIMD's issue slots ahead of its two neighbours, whose streaming work is latency-tolerant.
-                __builtin_amdgcn_s_setprio(3);
-#endif
                 // Rare (wave-uniform branch): exact float64 rows; class-cap (pod breaker) violations
                 // are projected in closed form inside the row; anything else goes to the slow kernel.
                 int st_gid[kSlots];
 #pragma unroll
                 for (int c = 0; c < kSlots; c++) st_gid[c] = valid[c] ? (int)(st_info[st[c]] & 0x7fu) : -1;
                 unsigned cap_viol;
-                bool anyviol;
-#ifdef EVC_RARE_TWICE        /* experiment (timing builds): the branch's body twice — the second pass runs on warm instruction cache lines */
-                double y_keep[kSlots];
-#pragma unroll
-                for (int c = 0; c < kSlots; c++) y_keep[c] = y[c];
-                unsigned long long t_rare2 = 0ull;
-#pragma unroll 1
-                for (int rep_ = 0; rep_ < 2; rep_++) {
-                if (rep_) {
-#pragma unroll
-                    for (int c = 0; c < kSlots; c++) y[c] = y_keep[c];
-                    t_rare2 = wall_clock64();
-                }
-#endif
-                // Shortcut (round 3): where the screen left only SIMPLE rows (class caps: pod breakers) open and the network's
-                // rows are monotone (Params::monotone_rows), the environment is settled by capping those classes — every
-                // other row was proven to hold at the box-clipped point and capping only lowers values.  One class-sum ladder
-                // per capped class instead of two evaluations of every row (before and after the water-filling): this IS the
-                // rare branch of a quiet day (0.3 % of the environments, 6 us per visit, and the launch ends with the last one).
-                const unsigned open_rows = (unsigned)(__ballot(maybe) >> (row * 16u)) & 0xffffu;
-                const bool caps_only = S.rare.monotone_rows != 0 && (open_rows & ~S.rare.simple_rows) == 0u;
-                const bool shortcut = __ballot(undecided && !caps_only) == 0ull;
-                if (shortcut) {
-                    cap_viol = 0u;
-                    const int G_ = S.rare.G;
-                    const unsigned capped = S.rare.cap_classes;
-                    for (int g = 0; g < G_; g++) {
-                        if (!((capped >> g) & 1u)) continue;
-                        double part = 0.0;
-#pragma unroll
-                        for (int c = 0; c < kSlots; c++) part += (st_gid[c] == g) ? y[c] : 0.0;
-                        if (row_allreduce_f64(part) > S.rare.class_cap[g] * (1.0 + Consts::PROJ_TOL)) cap_viol |= 1u << g;
-                    }
-                    anyviol = false;
-                } else {
-                    const bool hard = quad_exact_rows(S.rare.G, S.rare.class_cap, net, q, m, st_gid, y, undecided, cap_viol);
-                    anyviol = row_any(hard, row);
-                }
+                bool hard = quad_exact_rows(P.G, P.class_cap, net, q, m, st_gid, y, undecided, cap_viol);
+                bool anyviol = row_any(hard, row);
                 // Class caps are filled whenever one is violated, also beside violated multi-class rows:
                 // if the point projected onto box and caps satisfies every row it is the projection
                 // (relaxation argument); what remains violated goes to the slow kernel.
@@ -436,28 +360,18 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                     bool slot_cc[kSlots];
 #pragma unroll
                     for (int c = 0; c < kSlots; c++) slot_cc[c] = valid[c] && (st_info[st[c]] >> 7) != 0u;
-                    for (int g = 0; g < S.rare.G; g++) {
+                    for (int g = 0; g < P.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
-#ifdef EVC_WG_TIMING
-                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, S.rare.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr, &rare_sum2);
-#else
-                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, S.rare.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr);
-#endif
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr);
                     }
-                    if (!shortcut) {
-                        unsigned cv2;
-                        const bool still = row_any(quad_exact_rows(S.rare.G, S.rare.class_cap, net, q, m, st_gid, y, fill, cv2, S.rare.snap_tol), row);
-                        anyviol = anyviol && !(fill && !still);
-                    }
+                    unsigned cv2;
+                    const bool still = row_any(quad_exact_rows(P.G, P.class_cap, net, q, m, st_gid, y, fill, cv2, P.snap_tol), row);
+                    anyviol = anyviol && !(fill && !still);
                 }
-#ifdef EVC_RARE_TWICE
-                }
-                if (__ballot(row_any(maybe, row) && live) != 0ull) rare_sum2 += wall_clock64() - t_rare2;
-#endif
-                bool queue_me = undecided && anyviol;             // cones (or unsettled): the iterative solver
+                bool queue_me = undecided && anyviol;             // cones (or unsettled): slow kernel
                 bool list_full = false;
                 if (queue_me && q == 0u) {
-                    if (DRAIN == 1) {
+                    if (DRAIN) {
                         // The list holds every environment the workgroup steps (the engine launches this form only with
                         // quads_per_wave * 16 <= kDrainListMax, also under EVC_DRAIN=1), so it cannot be full; should a future
                         // launch shape break that, the environment is stepped with what the row could settle and FLAGGED
@@ -470,22 +384,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                         queue_push(P, (int)env);
                     }
                 }
-                if (DRAIN == 1) {
+                if (DRAIN) {
                     const bool full = row_any(list_full, row);
                     if (full) status |= EVC_STATUS_PROJ_NOCONV;
                     queue_me = queue_me && !full;
                 }
                 live = live && !queue_me;                 // queued rows write nothing here
                 pilots_screened = pilots_screened && !undecided;
-#ifndef EVC_NO_RARE_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef EVC_WG_TIMING
-                if (__ballot(row_any(maybe, row) && live) != 0ull) {          // (not the forced visits of EVC_WARM_RARE)
-                    const unsigned long long d_rare = wall_clock64() - t_rare;
-                    rare_sum += d_rare; rare_cnt += 1ull; rare_max = d_rare > rare_max ? d_rare : rare_max;
-                }
-#endif
             }
         }
 
@@ -791,20 +696,15 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         quad = quad_next;
     }
 
-    EVC_STAMP(2);
-    if (DRAIN == 1) {
+    if (DRAIN) {
         __syncthreads();                       // every wave's queue entries are in the list; the images are free
         const int count = S.local_count < kDrainListMax ? S.local_count : kDrainListMax;
-        if (__builtin_expect(count != 0, 0)) {            // all four wavefronts (drain_local_list hands out the entries)
+        if (__builtin_expect(count != 0, 0) && wv == 0u) {
 #ifndef EVC_ABL_DRAIN_NO_SOLVE      /* ablation builds only: the tail's own cost without the slow path's code */
             drain_local_list<WORDS>((unsigned)(size_t)(__attribute__((address_space(3))) void*)&S);
 #endif
         }
     }
-    EVC_STAMP(3);
-#ifdef EVC_WG_TIMING
-    if (lane == 0u && !DBG && P.N > 0) { wg_stamp[4] = rare_sum; wg_stamp[5] = rare_cnt; wg_stamp[6] = rare_max; wg_stamp[7] = rare_sum2; }
-#endif
 }
 
 }  // namespace evc

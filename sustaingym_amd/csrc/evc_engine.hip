@@ -364,12 +364,13 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                      action_kind == EVC_ACTION_GREEDY;
     // drain mode (see evc_engine): the lean compact streaming kernel can drain short queues itself
     // Who finishes the rows whose projection needs the iterative solver (lean compact streaming kernel):
-    //   1  the workgroup that queued them, from a list of its own once its streaming work is done (all four wavefronts);
+    //   1  the workgroup that queued them, from a list of its own once its streaming work is done;
     //   0  the slow kernel (a second launch) from the global queue — also every other kernel family.
     // Default: by the time of day, from the queue lengths the kernels report (below); EVC_DRAIN=0|1 forces a mode.
-    // Measured in round 3 and rejected: solving a row where it stands inside the period's body, and
-    // solving between two quads of the wavefront that queued it — the call's live ranges cost the streaming path 1.4 - 4 us
-    // per step and the launch still ends with the last solve's full latency.
+    // Measured in round 3 and rejected: all four wavefronts draining the list, solving a row where it
+    // stands inside the period's body, solving between two quads of the wavefront that queued it — a solve's latency
+    // (~20 us: dependent loads, the projection's ladders, finish_step) is what the launch waits for in every form, and a
+    // call inside the loop over quads costs the streaming path 1.4 - 4 us per step.
     bool drain = false;
     int mode = 0;
     if (e->P.project && e->use_quad && e->compact && !dbg && e->h_qlen) {

@@ -54,8 +54,11 @@ struct LdsRare {
     int monotone_rows, G;
 };
 __device__ __forceinline__ void stage_rare(LdsRare& r, const Params& P) {          // before a workgroup barrier
-    if (threadIdx.x < EVC_MAX_GROUPS) r.class_cap[threadIdx.x] = P.class_cap[threadIdx.x];
+    // one lane, uniform indices: the fields arrive through the scalar loads the kernel's other arguments take anyway (a
+    // lane-indexed copy is a VECTOR load from the kernel-argument segment: +0.4 us of prologue, measured)
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int g = 0; g < EVC_MAX_GROUPS; g++) r.class_cap[g] = P.class_cap[g];
         r.snap_tol = P.snap_tol; r.simple_rows = P.simple_rows; r.cap_classes = P.cap_classes;
         r.monotone_rows = P.monotone_rows; r.G = P.G;
     }

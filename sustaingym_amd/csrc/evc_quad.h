@@ -140,18 +140,25 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
     bool run = on;
     for (int it = 0; it < 80 && __ballot(run) != 0ull; it++) {
         if (pass_count) *pass_count += 1ull;
-        double part = 0.0, nextbp = 1e300;
+        double part = 0.0;
         unsigned nfree = 0u;
 #pragma unroll
         for (int j = 0; j < kSlots; j++) {
             const double v = b[j] - nu;
             part += in_g[j] ? fmin(fmax(v, 0.0), h[j]) : 0.0;
             nfree += (in_g[j] && v > 0.0 && v <= h[j] && h[j] > 0.0) ? 1u : 0u;
-            nextbp = fmin(nextbp, (in_g[j] && v > h[j]) ? b[j] - h[j] : 1e300);
         }
         const double f = row_allreduce_f64(part) - cap;
         const unsigned kfree = row_allreduce_u32(nfree);
-        const double bp = row_allreduce_min_f64(nextbp);
+        // the next breakpoint is needed only on a flat piece above the cap (every station of the class clamped at its
+        // upper bound): its min-ladder runs behind a wave-uniform branch instead of in every pass
+        double bp = 0.0;
+        if (__builtin_expect(__ballot(run && kfree == 0u && f > 0.0) != 0ull, 0)) {
+            double nextbp = 1e300;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) nextbp = fmin(nextbp, (in_g[j] && b[j] - nu > h[j]) ? b[j] - h[j] : 1e300);
+            bp = row_allreduce_min_f64(nextbp);
+        }
         if (run) {
             if (fabs(f) <= 1e-13 * cap) {
                 run = false;

@@ -7,8 +7,9 @@ os.environ.setdefault('SUSTAINGYM_AMD_LIB', os.path.join(ROOT, 'sustaingym_amd/v
 import numpy as np, torch
 import bench
 from sustaingym_amd import _lib
-w = bench.EvWorkload('caltech', 65536, 0, 0, project=True, phase='stagger')
-w.run(300)
+EP = os.environ.get('WG_EPISODES', 'synthetic')
+w = bench.EvWorkload(os.environ.get('WG_SITE', 'caltech'), 65536, 0, 0, project=True, episodes=EP, phase='stagger' if EP == 'synthetic' else 'sync')
+w.run(int(os.environ.get('WG_SKIP', '300')))
 torch.cuda.synchronize()
 lib = _lib.load()
 grid = 768
