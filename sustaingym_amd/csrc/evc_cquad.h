@@ -362,7 +362,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                     for (int c = 0; c < kSlots; c++) slot_cc[c] = valid[c] && (st_info[st[c]] >> 7) != 0u;
                     for (int g = 0; g < P.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
+#ifdef EVC_TRACE_FILL
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr, nullptr, env == (unsigned)(EVC_TRACE_FILL) && t == (EVC_TRACE_FILL_T));
+#else
                         if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr);
+#endif
                     }
                     unsigned cv2;
                     const bool still = row_any(quad_exact_rows(P.G, P.class_cap, net, q, m, st_gid, y, fill, cv2, P.snap_tol), row);

@@ -475,15 +475,18 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
 
 // The fused rollout (evc_rollout.h): `steps` periods of a device-resident policy in ONE launch.  Available for the
 // compact layout's quad geometry, when no per-station debug output is requested.
-bool fused_rollout_available(const evc_engine* e, int action_kind, const evc_step_out* out) {
-    if (action_kind != EVC_ACTION_GREEDY && action_kind != EVC_ACTION_RANDOM) return false;
+bool fused_rollout_available(const evc_engine* e, int action_kind, int ring_len, const evc_step_out* out) {
+    const bool replay = action_kind == EVC_ACTION_F32 || action_kind == EVC_ACTION_DISCRETE;
+    if (action_kind != EVC_ACTION_GREEDY && action_kind != EVC_ACTION_RANDOM && !replay) return false;
+    // a replayed ring is addressed with 32-bit byte offsets
+    if (replay && (double)ring_len * e->P.N * e->P.n * (action_kind == EVC_ACTION_DISCRETE ? 8.0 : 4.0) >= 4.0e9) return false;
     if (!e->use_quad || !e->compact) return false;
     if (out->pilots || out->rates || out->projected) return false;
     if (const char* s = getenv("EVC_ROLLOUT_FUSED")) return atoi(s) != 0;      // measurements / tests: 0 = the loop of steps
     return true;
 }
 
-int launch_rollout(evc_engine* e, int action_kind, int bins, int steps, const evc_step_out* out) {
+int launch_rollout(evc_engine* e, const void* actions_dev, int ring_len, int action_kind, int bins, int steps, const evc_step_out* out) {
     if (!out || !out->obs || !out->reward || !out->terminated)
         return fail(EVC_EINVAL, "evc_rollout: out->obs, out->reward, out->terminated required");
     if (action_kind == EVC_ACTION_RANDOM && bins == 1)
@@ -491,6 +494,9 @@ int launch_rollout(evc_engine* e, int action_kind, int bins, int steps, const ev
     RolloutIO io;
     io.policy = action_kind;
     io.bins = bins;
+    io.actions = actions_dev;
+    io.ring_len = ring_len > 0 ? ring_len : 1;
+    if (action_kind == EVC_ACTION_DISCRETE && bins < 2) return fail(EVC_EINVAL, "evc_rollout: discrete actions need bins >= 2");
     io.steps = steps;
     io.env_id_base = e->env_id_base;
     io.seed = e->policy_seed;
@@ -921,7 +927,8 @@ int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int
     if (!device_policy && (!actions_dev || ring_len < 1))
         return fail(EVC_EINVAL, "evc_rollout: actions and ring_len >= 1 required");
     if (int rc = bind(e)) return rc;
-    if (out && fused_rollout_available(e, action_kind, out)) return launch_rollout(e, action_kind, bins, steps, out);
+    if (out && fused_rollout_available(e, action_kind, ring_len, out))
+        return launch_rollout(e, actions_dev, ring_len, action_kind, bins, steps, out);
     const size_t elem = action_kind == EVC_ACTION_DISCRETE ? 8 : 4;
     const size_t stride = (size_t)e->P.N * e->P.n * elem;
     for (int i = 0; i < steps; i++) {

@@ -34,13 +34,19 @@ __device__ __forceinline__ unsigned row_allreduce_u32(unsigned v) {
     v += dpp_ror_u32<0x128>(v);   // row_ror:8
     return v;
 }
+// Sum over the 16 lanes of a row, IDENTICAL (bit for bit) on all of them: a butterfly — neighbours inside pairs, pairs inside
+// quads (quad_perm), quads inside halves (row_half_mirror), halves (row_mirror) — adds, at every level, the two halves of
+// a symmetric pair, and a + b == b + a exactly.  Rounds 1-2 used four rotations (row_ror 1, 2, 4, 8): the same cost, but
+// every lane then adds the sixteen values in its own order and the results differ in the last bits between lanes.  The
+// in-row water-filling branches on those sums per lane (bracket updates, the convergence test): on saturated / discrete
+// actions two lanes of a row took different branches and the Newton iteration settled on a point that met the cap with a
+// different multiplier per lane — found in round 3 by the replay form of the rollout tests (1 environment in 1022 x 628
+// steps; `tests/test_gpu_rollout.py`, `tools/scratch/ring_step_diff.py`).
 __device__ __forceinline__ double row_allreduce_f64(double v) {
-    // a rotation has no invalid source lane; bound_ctrl only tells the compiler that the destination's
-    // previous contents are dead (no v_mov 0 per half)
-    v += dpp_f64<0x121, 0xf, true>(v);
-    v += dpp_f64<0x122, 0xf, true>(v);
-    v += dpp_f64<0x124, 0xf, true>(v);
-    v += dpp_f64<0x128, 0xf, true>(v);
+    v += dpp_f64<0xB1, 0xf, true>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xf, true>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xf, true>(v);   // row_half_mirror
+    v += dpp_f64<0x140, 0xf, true>(v);   // row_mirror
     return v;
 }
 // does any lane of MY row have `flag` set?
@@ -126,7 +132,7 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
                                                const float (&act)[kSlots], const int (&dep)[kSlots],
                                                const double (&rem)[kSlots], double cap,
                                                double (&y)[kSlots], const bool (&is_cc)[kSlots], unsigned long long* counters,
-                                               unsigned long long* pass_count = nullptr) {
+                                               unsigned long long* pass_count = nullptr, bool trace = false) {
     // target b and cap h of every slot, once (slots that are compile-time empty fold away)
     double b[kSlots], h[kSlots];
     bool in_g[kSlots];
@@ -159,6 +165,9 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
             for (int j = 0; j < kSlots; j++) nextbp = fmin(nextbp, (in_g[j] && b[j] - nu > h[j]) ? b[j] - h[j] : 1e300);
             bp = row_allreduce_min_f64(nextbp);
         }
+#ifdef EVC_TRACE_FILL
+        if (trace) printf("fill g %d it %d lane %u run %d nu %.17g f %.17g kfree %u lo %.17g hi %.17g bp %.6g\n", g, it, (unsigned)__lane_id(), (int)run, nu, f, kfree, lo, hi, bp);
+#endif
         if (run) {
             if (fabs(f) <= 1e-13 * cap) {
                 run = false;

@@ -87,7 +87,8 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
 #define EVC_ROLLOUT_WAVES 3
 #endif
 
-template <bool PROJECT, int WORDS, bool RANDOM>
+// KIND: 0 = greedy, 1 = random (Philox), 2 = replay of a pre-staged action ring (evc_rollout with EVC_ACTION_F32 / _DISCRETE)
+template <bool PROJECT, int WORDS, int KIND>
 __global__ __launch_bounds__(256, EVC_ROLLOUT_WAVES) void rollout_kernel(Params P, RolloutIO io) {
     __shared__ RolloutLds S;
     LdsNet& net = S.net;
@@ -217,6 +218,27 @@ __global__ __launch_bounds__(256, EVC_ROLLOUT_WAVES) void rollout_kernel(Params 
         lds_sync();
     };
 
+    constexpr bool RANDOM = KIND != 0;                            // actions come through the action image (drawn or replayed)
+    // replay: lane q of a row fetches stations 4q..4q+3 of its environment's action row, one period ahead
+    const bool discrete_in = KIND == 2 && io.policy == EVC_ACTION_DISCRETE;
+    const unsigned act_elem = discrete_in ? 8u : 4u;
+    const rsrc_t r_ring = row_rsrc(KIND == 2 ? io.actions : nullptr, KIND == 2 ? (unsigned)io.ring_len * N * n * act_elem : 0u);
+    auto fetch_actions = [&](int step_) {
+        v4u raw;
+        const unsigned base = ((unsigned)(step_ % io.ring_len) * N + env) * n;
+        const unsigned w[4] = {0u, 0u, 0u, 0u};
+        (void)w;
+        unsigned r4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned s_ = 4u * q + (unsigned)j;
+            r4[j] = buf_ld_u32(r_ring, (KIND == 2 && ev && step_ < io.steps && s_ < n) ? (base + s_) * act_elem : kOob);
+        }
+        raw.x = r4[0]; raw.y = r4[1]; raw.z = r4[2]; raw.w = r4[3];
+        return raw;
+    };
+    v4u act_next = fetch_actions(0);
+
     for (int step = 0; step < io.steps; step++) {
         const bool after_done = ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
         const bool live = ev && !after_done;
@@ -231,8 +253,24 @@ __global__ __launch_bounds__(256, EVC_ROLLOUT_WAVES) void rollout_kernel(Params 
         v2u sv = buf_ld_v2(r_sess, pending ? sidx * 8u : kOob);
         double rq = buf_ld_f64(r_req, pending ? sidx * 8u : kOob);
 
+        if (KIND == 2) {                                        // replayed actions: clamp like evc_step (NaN -> 0, flag)
+            const v4u raw = act_next;
+            act_next = fetch_actions(step + 1);
+            const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w};
+            float a[4];
+            bool clamped = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float in = discrete_in ? (float)(int)rw[j] / (float)(io.bins - 1) : __uint_as_float(rw[j]);   // wrappers.py:43-45
+                a[j] = fminf(fmaxf(in, 0.0f), 1.0f);
+                clamped = clamped || (4u * q + (unsigned)j < n && a[j] != in);
+            }
+            if (live && row_any(clamped, row)) status |= EVC_STATUS_ACTION_CLAMPED;
+            *reinterpret_cast<float4*>(&act_row[4u * q]) = make_float4(a[0], a[1], a[2], a[3]);
+            lds_sync();
+        }
         // action image of the random policy: lane q draws stations 4q..4q+3 of its row
-        if (RANDOM) {
+        if (KIND == 1) {
             float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (live && q < blocks_per_env) {
                 const Philox ph((unsigned)t | (q << 16), (unsigned)episodes, io.env_id_base + env, kPolicyTag,
@@ -349,7 +387,7 @@ __global__ __launch_bounds__(256, EVC_ROLLOUT_WAVES) void rollout_kernel(Params 
                         if (solve_me && valid[c]) img_row[st[c]].h_or_y = quad_demand_cap(dep[c], rem[c]);
                     const unsigned rows = ((solve_mask & 0xffffull) ? 1u : 0u) | ((solve_mask & 0xffff0000ull) ? 2u : 0u) |
                                           ((solve_mask & 0xffff00000000ull) ? 4u : 0u) | ((solve_mask >> 48) ? 8u : 0u) |
-                                          (RANDOM ? 16u : 0u);
+                                          (KIND != 0 ? 16u : 0u);
                     lds_sync();
                     rollout_solve_rows((unsigned)(size_t)(__attribute__((address_space(3))) void*)&S, wv, rows);
                     lds_sync();

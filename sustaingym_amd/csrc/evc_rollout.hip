@@ -9,20 +9,24 @@ namespace evc {
 
 bool launch_rollout_kernel(const Params& P, const RolloutIO& io, int grid, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
     const int words = (P.G + 1) / 2;
-    const bool random = io.policy == EVC_ACTION_RANDOM;
+    const int kind = io.policy == EVC_ACTION_GREEDY ? 0 : (io.policy == EVC_ACTION_RANDOM ? 1 : 2);
     auto launch = [&](auto kernel) {
         if (start && stop) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, stream, start, stop, 0, P, io);
         else hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, stream, P, io);
     };
+#define EVC_ROLL_P(PROJ, W)                                                                         \
+        if (kind == 0) launch(rollout_kernel<PROJ, W, 0>);                                          \
+        else if (kind == 1) launch(rollout_kernel<PROJ, W, 1>);                                     \
+        else launch(rollout_kernel<PROJ, W, 2>);
 #define EVC_ROLL(W)                                                                                 \
     case W:                                                                                         \
-        if (P.project) { if (random) launch(rollout_kernel<true, W, true>); else launch(rollout_kernel<true, W, false>); }    \
-        else { if (random) launch(rollout_kernel<false, W, true>); else launch(rollout_kernel<false, W, false>); }            \
+        if (P.project) { EVC_ROLL_P(true, W) } else { EVC_ROLL_P(false, W) }                        \
         return true;
     switch (words) {
         EVC_ROLL(1) EVC_ROLL(2) EVC_ROLL(3) EVC_ROLL(4) EVC_ROLL(5) EVC_ROLL(6) EVC_ROLL(7) EVC_ROLL(8)
         default: return false;
     }
+#undef EVC_ROLL_P
 #undef EVC_ROLL
 }
 

@@ -9,15 +9,17 @@
 namespace evc {
 
 struct RolloutIO {
-    int policy;                  // EVC_ACTION_GREEDY / EVC_ACTION_RANDOM
-    int bins;                    // RANDOM: >= 2 draws DiscreteActionWrapper levels
+    int policy;                  // EVC_ACTION_GREEDY / EVC_ACTION_RANDOM, or EVC_ACTION_F32 / EVC_ACTION_DISCRETE = replay of `actions`
+    int bins;                    // RANDOM: >= 2 draws DiscreteActionWrapper levels; DISCRETE: the wrapper's bins
+    const void* actions;         // replay: [ring_len][N][n] float32 (F32) / int64 levels (DISCRETE); period i reads slice i mod ring_len
+    int ring_len;
     int steps;                   // T
     unsigned env_id_base;        // global id of environment 0 (random stream)
     unsigned long long seed;     // random stream key
     evc_step_out out;
 };
 
-// Launches rollout_kernel<P.project, (P.G + 1) / 2, io.policy == EVC_ACTION_RANDOM> on `stream`; with start / stop events
+// Launches rollout_kernel<P.project, (P.G + 1) / 2, policy kind (0 greedy, 1 random, 2 replay)> on `stream`; with start / stop events
 // the launch carries them (hipExtLaunchKernel: the dispatch's own begin / end timestamps).  false: unsupported class count.
 bool launch_rollout_kernel(const Params& P, const RolloutIO& io, int grid, hipStream_t stream, hipEvent_t start, hipEvent_t stop);
 

@@ -34,11 +34,27 @@ def _moer_days(site, period):
     return synthetic_moer(gmm_device_tables(site, period)['num_days'], seed=3)
 
 
+def _ring(eng, policy, bins):
+    """A pre-staged action ring for the replay form of evc_rollout: 5 slices; the float ring holds a NaN, a negative and a
+    > 1 entry (clamped and flagged like evc_step does)."""
+    import torch
+    g = torch.Generator(device='cuda')
+    g.manual_seed(5)
+    if policy == 'ringd':
+        return torch.randint(0, bins, (5, eng.N, eng.n), device='cuda', generator=g, dtype=torch.int64)
+    a = torch.rand((5, eng.N, eng.n), device='cuda', generator=g, dtype=torch.float32)
+    a[1, 3, 2], a[2, 7, 0], a[3, 11, eng.n - 1] = float('nan'), -0.25, 1.5
+    return a
+
+
 def _run(eng, policy, steps, bins, fused):
     import torch
     os.environ['EVC_ROLLOUT_FUSED'] = '1' if fused else '0'
     try:
-        out = eng.rollout(policy=policy, steps=steps, bins=bins)
+        if policy in ('ring', 'ringd'):
+            out = eng.rollout(actions=_ring(eng, policy, bins), steps=steps, bins=bins if policy == 'ringd' else 0)
+        else:
+            out = eng.rollout(policy=policy, steps=steps, bins=bins)
         torch.cuda.synchronize()
     finally:
         os.environ.pop('EVC_ROLLOUT_FUSED', None)
@@ -48,7 +64,8 @@ def _run(eng, policy, steps, bins, fused):
 @pytest.mark.parametrize('site,policy,bins,project', [
     ('caltech', 'random', 0, True), ('caltech', 'greedy', 0, True), ('jpl', 'random', 0, True),
     ('jpl', 'greedy', 0, True), ('caltech', 'random', 5, True), ('caltech', 'random', 0, False),
-    ('jpl', 'greedy', 0, False)])
+    ('jpl', 'greedy', 0, False), ('caltech', 'ring', 0, True), ('jpl', 'ring', 0, True), ('caltech', 'ringd', 5, True),
+    ('caltech', 'ring', 0, False)])
 def test_fused_rollout_equals_the_loop_of_steps(site, policy, bins, project):
     """One launch of T periods == T launches of one period: every piece of simulator state and every output,
     for T = 1, a stretch of the congested morning, a whole day, and across an autoreset boundary."""
@@ -82,6 +99,8 @@ def test_fused_rollout_equals_the_loop_of_steps(site, policy, bins, project):
         np.testing.assert_allclose(a['returns'], b['returns'], rtol=1e-12, atol=1e-13, err_msg=tag)
     assert (sa['scalars'][:, 7] >= 2).all()               # two episodes finished everywhere
     assert not (sa['scalars'][:, 6] & 2).any()            # EVC_STATUS_PROJ_NOCONV never
+    if policy == 'ring':
+        assert (sa['scalars'][[3, 7, 11], 6] & 8).all() and int(((sa['scalars'][:, 6] & 8) != 0).sum()) == 3      # EVC_STATUS_ACTION_CLAMPED
     for eng in engines:
         eng.close()
 
@@ -150,3 +169,31 @@ def test_fused_rollout_mid_episode_and_after_done():
     assert (sc['status'] & 4).all() and (sc['t'] == 288).all()       # EVC_STATUS_STEP_AFTER_DONE
     assert np.array_equal(gg['obs'][:, n:], oo['obs'][:, n:])
     eng.close()
+
+
+def test_discrete_ring_on_gmm_days_against_the_oracle():
+    """The case that exposed a lane-dependent branch in the in-row water-filling (rounds 1-2: the row sums differed in
+    their last bits between the lanes of a row, csrc/evc_quad.h row_allreduce_f64): DiscreteActionWrapper levels — equal
+    targets, saturated pods — replayed on GMM days, the STEP kernels and the fused kernel against the oracle."""
+    site, bins, N, bank, period = 'caltech', 5, 1022, 2048, 'Summer 2019'
+    rets = {}
+    for fused in (True, False):
+        net, eng = _gmm_engine(site, period, N, bank, seed=77, project=True, autoreset=True)
+        eng.set_autoreset_stride(N)
+        eng.reset()
+        ring = to_host(_ring(eng, 'ringd', bins)).copy()
+        rets[fused] = [_run(eng, 'ringd', steps, bins, fused)['returns'] for steps in (96, 192, 340)]
+        if fused:
+            ns, sess, req, day, _ = eng.download_episodes(0, bank)
+        assert not (eng.env_scalars()['status'] & 2).any()
+        eng.close()
+    bat = ob.OracleBatch(ob.OracleNetwork(net), N, 36, True)
+    bat.set_bank(ns, sess, req, day, _moer_days(site, period), autoreset_stride=N)
+    bat.reset()
+    for ci, steps in enumerate((96, 192, 340)):
+        ret = np.zeros(N)
+        for i in range(steps):
+            ret += bat.step(ring[i % 5], bins=bins, autoreset=True, debug=False)['reward']
+        for fused in (True, False):
+            np.testing.assert_allclose(rets[fused][ci], ret, rtol=1e-9, atol=1e-12, err_msg=f'chunk {ci} fused={fused}')
+
