@@ -401,11 +401,24 @@ def secondary_rollout(policy, dev_index, battery, episodes='synthetic') -> dict:
     bat.rollout(policy, obs0, steps=EPISODE, seed=7, threads=cores)
     cpu = time.perf_counter() - t0
     w.close()
+    # The fused kernel has no HBM traffic to speak of (one MOER value and the arriving session records per environment-period):
+    # its bound is VALU issue.  Instructions per env-step come from the SQ counters of tools/profile_rollout.sh
+    # (profiles/r3_rollout_*.json); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md).
+    valu = None
+    try:
+        valu = json.load(open(os.path.join(ROOT, 'profiles', f'r3_rollout_caltech_{"synthetic" if episodes == "synthetic" else "gmm"}_{policy}.json')))['SQ_INSTS_VALU']
+    except Exception:
+        pass
+    peak = 256 * 4 * 2.4e9 / 2
+    roof = None if valu is None else {'bound': 'valu', 'valu_instructions_per_env_step': valu,
+                                      'achieved': round(N * EPISODE / (kernel_ms * 1e-3) * valu / 1e9, 1), 'peak': round(peak / 1e9, 1),
+                                      'unit': 'G wave-instructions/s', 'frac': round(N * EPISODE / (kernel_ms * 1e-3) * valu / peak, 4),
+                                      'note': 'float64 instructions issue at half this rate; SQ_ACTIVE_INST_VALU says the vector ALUs are busy ~68 % of the launch (DESIGN.md 4.6)'}
     return {'workload': f'{N} x {w.n}-station (caltech), {"synthetic days" if episodes == "synthetic" else "device-generated GMM days"}, '
                         f'projection on, {policy} policy on the device, whole episodes (288 periods), autoreset',
             'env_steps_per_s': round(N * EPISODE / fused, 1), 'episode_ms': round(fused * 1e3, 4),
             'us_per_period': round(fused / EPISODE * 1e6, 3), 'launches_per_episode': 1,
-            'kernel': 'evc::rollout_kernel', 'kernel_ms': round(kernel_ms, 4),
+            'kernel': 'evc::rollout_kernel', 'kernel_ms': round(kernel_ms, 4), 'roofline': roof,
             'loop_of_steps': {'env_steps_per_s': round(N * EPISODE / loop, 1), 'episode_ms': round(loop * 1e3, 3),
                               'launches_per_episode': EPISODE * (2 if policy == 'random' else 1) + 0,
                               'note': 'EVC_ROLLOUT_FUSED=0: evc_step per period (random: + the action kernel), observations written every period'},

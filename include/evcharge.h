@@ -224,11 +224,16 @@ int evc_reset(evc_engine* e, const int32_t* env_ids, int32_t count, const int32_
 int evc_step(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
              const evc_step_out* out);
 
-/* Runs `steps` consecutive evc_step calls back to back on the engine's stream without returning to
- * the host in between (device-resident policy or pre-staged actions): step i reads its actions at
- * actions_dev + (i mod ring_len) * N * n elements (ignored for EVC_ACTION_GREEDY).  Outputs are those
- * of the last step; out->returns accumulates over all steps.  Counterpart of the episode loop of
- * BaseAlgorithm.run (algorithms/base.py:63-88). */
+/* `steps` consecutive evc_step calls without returning to the host in between (device-resident policy
+ * or pre-staged actions): step i reads its actions at actions_dev + (i mod ring_len) * N * n elements
+ * (ignored for EVC_ACTION_GREEDY / _RANDOM).  Outputs are those of the LAST step (obs, reward, terminated,
+ * breakdown; final_obs of episodes that ended inside the call); out->returns accumulates every reward.
+ * Counterpart of the episode loop of BaseAlgorithm.run (algorithms/base.py:63-88).
+ * On the default (compact) state layout, with no per-station debug output requested, the whole call is
+ * ONE kernel launch (csrc/evc_rollout.h): a wavefront keeps its four environments' state in registers
+ * for all `steps` periods, draws / reads the actions itself, and writes state and outputs once at the
+ * end — results identical to the loop of evc_step calls (tests/test_gpu_rollout.py).  EVC_ROLLOUT_FUSED=0
+ * in the environment selects the loop (measurements). */
 int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
                 int32_t steps, int32_t ring_len, const evc_step_out* out);
 

@@ -197,3 +197,33 @@ def test_discrete_ring_on_gmm_days_against_the_oracle():
         for fused in (True, False):
             np.testing.assert_allclose(rets[fused][ci], ret, rtol=1e-9, atol=1e-12, err_msg=f'chunk {ci} fused={fused}')
 
+
+@pytest.mark.parametrize('site,fused', [('caltech', True), ('caltech', False), ('jpl', True), ('jpl', False)])
+def test_discrete_ring_16384_gmm_days_against_the_oracle(site, fused):
+    """A whole GMM day of 16 384 environments under replayed DiscreteActionWrapper levels (ties and saturated pods in
+    nearly every period), through the fused kernel and through the loop of step kernels: returns, breakdowns, final
+    station state against the oracle stepped with the same ring."""
+    bins, N = 5, 16384
+    period = 'Summer 2019' if site == 'caltech' else 'Summer 2021'
+    net, eng = _gmm_engine(site, period, N, N, seed=4321)
+    n = net.num_stations
+    ns, sess, req, day, _ = eng.download_episodes(0, N)
+    bat = ob.OracleBatch(ob.OracleNetwork(net), N, 36, True)
+    bat.set_bank(ns, sess, req, day, _moer_days(site, period))
+    assert np.array_equal(to_host(eng.reset()), bat.reset())
+    ring = to_host(_ring(eng, 'ringd', bins)).copy()
+    g = _run(eng, 'ringd', 288, bins, fused)
+    ret = np.zeros(N)
+    for i in range(288):
+        o = bat.step(ring[i % 5], bins=bins, debug=False)
+        ret += o['reward']
+    np.testing.assert_allclose(g['returns'], ret, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(g['breakdown'], o['breakdown'], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(g['obs'][:, n:], o['obs'][:, n:])
+    rem, dep, est = eng.station_state()
+    o_rem, o_dep, o_est = bat.station_state()
+    assert np.array_equal(dep, o_dep) and np.array_equal(est, o_est)
+    np.testing.assert_allclose(rem, o_rem, rtol=1e-9, atol=1e-10)
+    assert not (eng.env_scalars()['status'] & 2).any()
+    eng.close()
+

@@ -1,6 +1,6 @@
 """One (or a few) fused rollouts of one configuration, for profiling: site episodes policy [N] [reps]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from bench import EvWorkload

@@ -7,6 +7,10 @@ TAG=${1:-prof}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
+# the plain run FIRST: counter collection leaves the GPU in a lower, fixed clock state for a while (MI355X_MICROARCH.md, DVFS:
+# "never compare a profiled arm with an un-profiled one") — a plain bench run after the PMC passes read 33 us per step on a
+# box whose undisturbed figure was 26.5
+python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
     python $REPO/bench.py --steps 288 --warmup 96 --no-cpu-baseline --no-secondary > $OUT/bench_traced.json 2> $OUT/trace.err
@@ -15,6 +19,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- \
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- \
     python $REPO/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-secondary --kernel-timing-steps 1 > /dev/null 2> $OUT/pmc_write.err
 cd $REPO
-python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 python tools/summarize_profile.py $OUT $REPO/gpurun_out/${TAG}
 cat $OUT/bench_plain.json
