@@ -65,6 +65,10 @@ def parse_args(argv=None):
     p.add_argument('--no-project', action='store_true', help='project_action_in_env=False')
     p.add_argument('--bank', type=int, default=8192, help='distinct episodes resident in HBM')
     p.add_argument('--ring', type=int, default=8, help='distinct action batches resident in HBM')
+    p.add_argument('--pipeline', type=int, default=2, choices=[1, 2],
+                   help='2 (default): the batch stepped as two half-batch launches on two streams whose tails overlap the '
+                        "next launches (evc_set_pipeline; the action ring is resident, nothing reads an output between steps); "
+                        '1: one launch per step, every step ordered on one stream')
     p.add_argument('--phase', default='stagger', choices=['stagger', 'sync'],
                    help="'stagger' (default): episode phases spread uniformly over the day, every step costs the "
                         "day's average; 'sync': all episodes start together")
@@ -121,7 +125,7 @@ class EvWorkload:
     """Engine + episode bank + action ring for N environments on `dev`, phases set up as asked."""
 
     def __init__(self, site, N, dev_index, rank, project=True, episodes='synthetic', bank=8192, ring=8, busy=False,
-                 phase='stagger', battery='continuous', seed_base=1000):
+                 phase='stagger', battery='continuous', seed_base=1000, pipeline=2):
         import torch
         from sustaingym_amd.engine import StepEngine
         from sustaingym_amd.network import site_str_to_site
@@ -164,6 +168,11 @@ class EvWorkload:
         self.ptrs = [t.data_ptr() for t in self.ring]
         eng.reset()
         self.step, self.out = eng.make_stepper()
+        # pipelined halves (evc_set_pipeline): the action ring is staged once, nothing reads an output between steps, so the
+        # two half-batches may run ahead of each other; every reader below joins first (any engine call does)
+        self.pipeline = pipeline
+        if pipeline == 2:
+            eng.set_pipeline(2)
         self._i = 0
         if phase == 'stagger':
             self._stagger()
@@ -202,8 +211,33 @@ class EvWorkload:
             if self.project:
                 slow_cnt.append(eng.last_slow_count())
         eng.enable_timing(False)
-        return {'main_ms': np.array(main_ms), 'slow_ms': np.array(slow_ms),
-                'slow_envs': float(np.mean(slow_cnt)) if slow_cnt else 0.0}
+        res = {'main_ms': np.array(main_ms), 'slow_ms': np.array(slow_ms),
+               'slow_envs': float(np.mean(slow_cnt)) if slow_cnt else 0.0, 'period_ms': None, 'half_ms': None}
+        before = eng.pipelined_steps()
+        self.run(8)
+        if eng.pipelined_steps() - before == 8:
+            # Pipelined halves: a step is two launches that overlap the neighbouring steps' — what the GPU needs per step is
+            # the PERIOD of the launch train, measured with HIP events on the stream that joins it (windows of M steps;
+            # the first record makes the stream busy, so the window's first step is ordered behind it like a caller's
+            # actions would be), and a half launch's own begin-to-end time under that overlap (what a kernel trace shows).
+            torch = self.torch
+            M = 96
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            periods, halves = [], []
+            for _ in range(max(3, launches // M)):
+                e0.record()
+                self.run(M)
+                eng.join()
+                e1.record()
+                e1.synchronize()
+                periods.append(e0.elapsed_time(e1) / M)
+            eng.enable_timing(True)
+            for _ in range(24):
+                self.run(6)
+                halves.extend(eng.last_half_ms())
+            eng.enable_timing(False)
+            res['period_ms'], res['half_ms'] = np.array(periods), np.array(halves)
+        return res
 
     def wall_ms_per_step(self, steps: int) -> float:
         torch = self.torch
@@ -211,6 +245,7 @@ class EvWorkload:
         t0 = time.perf_counter()
         self.run(steps)
         self.host_issue_ms_per_step = (time.perf_counter() - t0) / steps * 1e3      # how long the host took to enqueue them
+        self.eng.join()
         torch.cuda.synchronize(self.dev)
         return (time.perf_counter() - t0) / steps * 1e3
 
@@ -245,7 +280,7 @@ def code_object_hash(symbol: bytes = b'step_kernel_cquad') -> str | None:
     return None
 
 
-def lookup_traffic(site, N, project, layout):
+def lookup_traffic(site, N, project, layout, launches_per_step=1):
     """HBM bytes per launch of the streaming kernel from the PMC passes of tools/profile.sh (profiles/traffic.json:
     FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs, corrected as DESIGN.md §6 describes).  The entry records
     the hash of the code object it was measured on: a library built from different kernels gets `None` (and the
@@ -258,17 +293,25 @@ def lookup_traffic(site, N, project, layout):
         have = code_object_hash()
         if ent and ent.get('code_object_sha256') != have:
             return None, f"profiles/traffic.json was measured on code object {ent.get('code_object_sha256')}, this library is {have}: re-run tools/profile.sh"
-        return ent.get('hbm_bytes_per_launch'), ent.get('source')
+        per_launch, lps = ent.get('hbm_bytes_per_launch'), ent.get('launches_per_step', 1)
+        if per_launch is None:
+            return None, ent.get('source')
+        if lps != launches_per_step:
+            return None, f'profiles/traffic.json was measured with {lps} launch(es) per step, this run uses {launches_per_step}: re-run tools/profile.sh'
+        return per_launch * lps, ent.get('source')        # bytes per STEP (= per launch when a step is one launch)
     except Exception:
         return None, None
 
 
 def roofline_record(w: EvWorkload, timed: dict, bytes_per_env_step: int) -> dict:
     layout = os.environ.get('EVC_LAYOUT', 'compact')          # engine default
-    avg = float(timed['main_ms'].mean())
+    pipelined = timed.get('period_ms') is not None
+    # one launch per step: the launch's own duration.  Pipelined halves: the period of the launch train (a step's two
+    # launches overlap the neighbouring steps', so a launch's own duration is not what the GPU needs per step)
+    avg = float(timed['period_ms'].mean()) if pipelined else float(timed['main_ms'].mean())
     alg = bytes_per_env_step * w.N
     achieved = alg / (avg * 1e-3) / 1e9
-    traffic, source = lookup_traffic(w.site, w.N, w.project, layout)
+    traffic, source = lookup_traffic(w.site, w.N, w.project, layout, 2 if pipelined else 1)
     rec = {'bound': 'hbm', 'kernel': 'evc::step_kernel_cquad' if layout == 'compact' else 'evc::step_kernel_quad',
            'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
            'traffic': traffic,
@@ -284,6 +327,20 @@ def roofline_record(w: EvWorkload, timed: dict, bytes_per_env_step: int) -> dict
            'solver_kernel_ms': round(float(timed['slow_ms'].mean()), 5),
            'slow_queue_envs_per_step': round(timed['slow_envs'], 1),
            'algorithmic_bytes_per_launch': alg}
+    if pipelined:
+        h = timed['half_ms']
+        rec.update({
+            'launches_per_step': 2, 'algorithmic_bytes_per_launch': alg // 2, 'algorithmic_bytes_per_step': alg,
+            'basis': 'achieved = algorithmic bytes per STEP / step period.  A step is two half-batch launches on two streams '
+                     '(evc_set_pipeline) that overlap the neighbouring steps\' launches; step_period_ms = HIP events on the joining '
+                     'stream over windows of 96 steps; half_launch_ms = one launch\'s own begin-to-end time under that overlap '
+                     '(hipExtLaunchKernel events; what a kernel trace reports per dispatch); step_alone_ms = first begin to last end '
+                     'of a step issued alone',
+            'step_period_ms': round(avg, 5), 'avg_kernel_ms': round(float(h.mean()), 5),
+            'kernel_ms_min_max': [round(float(h.min()), 5), round(float(h.max()), 5)], 'kernel_launches_timed': int(len(h)),
+            'half_launch_ms': round(float(h.mean()), 5),
+            'step_alone_ms': round(float(timed['main_ms'].mean()), 5),
+            'step_period_ms_min_max': [round(float(timed['period_ms'].min()), 5), round(float(timed['period_ms'].max()), 5)]})
     return rec
 
 
@@ -340,11 +397,17 @@ def secondary_days(site, episodes, dev_index, battery) -> dict:
     w = EvWorkload(site, 65536, dev_index, 0, project=True, episodes=episodes, phase='sync', battery=battery)
     w.run(EPISODE)                                   # one untimed day; the timed one starts at an episode boundary
     wall = w.wall_ms_per_step(EPISODE)               # one whole synchronised day (what a vector env plays)
+    split = w.eng.pipelined_steps()
+    w.eng.set_pipeline(1)                            # the same day as one launch per step, and its kernels by time of day
+    wall1 = w.wall_ms_per_step(EPISODE)
     timed = w.time_kernels(EPISODE)
     alg = algorithmic_bytes_per_env_step(w.n, w.k)
     what = 'device-generated GMM days' if episodes == 'gmm' else f'the {w.P} ACN-Data days of Summer 2021 (RealTraceBank), real MOER'
     rec = {'workload': f'65536 x {w.n}-station ({site}) on {what}, projection on, U[0,1) actions, synchronised episodes, mean over one whole day',
            'ms_per_step': round(wall, 5), 'env_steps_per_s': round(65536 / wall * 1e3, 1),
+           'pipelined_steps_of_the_day': int(split - EPISODE) if split >= EPISODE else int(split),
+           'single_launch': {'ms_per_step': round(wall1, 5), 'env_steps_per_s': round(65536 / wall1 * 1e3, 1),
+                             'note': 'evc_set_pipeline(1): one launch per step; the kernel times below are of this form'},
            'kernel_us': round(float(timed['main_ms'].mean()) * 1e3, 2),
            'kernel_us_by_4h': [round(float(x.mean()) * 1e3, 1) for x in np.array_split(timed['main_ms'], 6)],
            'solver_kernel_us': round(float(timed['slow_ms'].mean()) * 1e3, 2),
@@ -693,7 +756,7 @@ def main():
     N = args.envs_per_gpu if args.scaling == 'weak' else max(4, args.global_envs // world)
     project = not args.no_project
     w = EvWorkload(args.site, N, local_rank, rank, project=project, episodes=args.episodes, bank=args.bank,
-                   ring=args.ring, busy=args.busy, phase=args.phase, battery=args.battery)
+                   ring=args.ring, busy=args.busy, phase=args.phase, battery=args.battery, pipeline=args.pipeline)
     n, k = w.n, w.k
 
     def barrier():
@@ -705,12 +768,15 @@ def main():
     w.run(args.warmup)
     barrier()
     steps0 = w.eng.read_metrics()['env_steps']
+    pipelined0 = w.eng.pipelined_steps()
     t0 = time.perf_counter()
     w.run(args.steps)
+    w.eng.join()                 # the engine's stream waits for both half launches; barrier() then drains the device
     barrier()
     local_elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(local_elapsed, coll_dev)
     timed_env_steps = w.eng.read_metrics()['env_steps'] - steps0
+    pipelined_timed = w.eng.pipelined_steps() - pipelined0
 
     # ---- metrics all-gather (the only collective of the path; off the step critical path) ----
     # With synchronised phases the accumulators are per running episode (env.py:329-338 zeroes them at reset)
@@ -727,7 +793,7 @@ def main():
     if world > 1 and args.scaling == 'weak':
         Ns = max(4, args.global_envs // world)
         ws = EvWorkload(args.site, Ns, local_rank, rank, project=project, episodes=args.episodes, bank=args.bank,
-                        ring=args.ring, busy=args.busy, phase=args.phase, battery=args.battery)
+                        ring=args.ring, busy=args.busy, phase=args.phase, battery=args.battery, pipeline=args.pipeline)
         ws.run(args.warmup)
         barrier()
         t1 = time.perf_counter()
@@ -743,7 +809,18 @@ def main():
     if rank == 0:
         timed = w.time_kernels(args.kernel_timing_steps)
         roofline = roofline_record(w, timed, algorithmic_bytes_per_env_step(n, k))
-        roofline['launch_overhead_ms'] = round(elapsed / args.steps * 1e3 - roofline['avg_kernel_ms'], 5)
+        roofline['launch_overhead_ms'] = round(elapsed / args.steps * 1e3 - roofline.get('step_period_ms', roofline['avg_kernel_ms']), 5)
+        if w.pipeline == 2:
+            # the same workload as ONE launch per step (evc_set_pipeline(1)), for continuity with rounds 1-2
+            w.eng.set_pipeline(1)
+            w.run(32)
+            single_ms = w.wall_ms_per_step(max(args.steps, 288))
+            t1 = w.time_kernels(args.kernel_timing_steps)
+            roofline['single_launch'] = {'ms_per_step': round(single_ms, 5), 'env_steps_per_s': round(N / single_ms * 1e3, 1),
+                                         'avg_kernel_ms': round(float(t1['main_ms'].mean()), 5),
+                                         'frac': round(roofline['algorithmic_bytes_per_step' if 'algorithmic_bytes_per_step' in roofline
+                                                                else 'algorithmic_bytes_per_launch'] / (float(t1['main_ms'].mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            w.eng.set_pipeline(2)
     if rank == 0:
         # Reset-path row: refill the whole episode bank with the on-device GMM generator
         # (after the timed region; the bank is not used again).
@@ -804,7 +881,10 @@ def main():
                                    + tags,
                        'envs_per_gpu': N, 'global_envs': N * world, 'parallelism': f'env-shard x{world}',
                        'actions': 'U[0,1) float32 resident in HBM', 'battery_model': args.battery,
-                       'phase': args.phase},
+                       'phase': args.phase,
+                       'pipeline': ('2 half-batch launches per step on 2 streams (evc_set_pipeline): all outputs of every step written, '
+                                    'the halves\' launches overlap across steps' if w.pipeline == 2 else '1 launch per step'),
+                       'pipelined_steps_timed': int(pipelined_timed)},
             # proof that `world` ranks stepped: gathered over the process group
             'ranks_seen': int(per_rank.shape[0]),
             'per_rank': {'value': [round(N * args.steps / e, 1) for e in per_rank[:, 6]],

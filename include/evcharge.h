@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 3
+#define EVC_ABI_VERSION 4
 
 #define EVC_MAX_STATIONS     64   /* one gfx950 wavefront per environment            */
 #define EVC_MAX_CONSTRAINTS  32   /* rows of ChargingNetwork.constraint_matrix       */
@@ -149,6 +149,25 @@ int evc_abi_version(void);
 /* Orders all subsequent engine work on `hip_stream` (a hipStream_t; NULL = default). */
 int evc_set_stream(evc_engine* e, void* hip_stream);
 int evc_synchronize(evc_engine* e);
+
+/* Pipelined halves (throughput loops; no counterpart in the reference, whose vector env is a set of processes).
+ * halves = 2: evc_step on device buffers with the lean outputs (obs / reward / terminated / breakdown / final_obs), float32
+ * actions and at least 2 x 4 quads per wavefront of the grid steps the batch as TWO launches — environments [0, N/2) and
+ * [N/2, N) — on two internal streams.  Both wait for the work the engine's stream holds when evc_step is called (the
+ * caller's actions: one event, skipped when that stream is idle) and consecutive steps of one half are ordered; the two
+ * halves are NOT ordered with each other and
+ * the engine's stream does not wait for them: a launch's tail — the few wavefronts still in the rare projection branch —
+ * runs under the other half's next launch (2 x 32 768 environments: 22.6 instead of 26.4 us per 65 536 environment-steps
+ * on MI355X).  The price is the contract: outputs are complete on the engine's stream only after evc_join (every other
+ * entry point joins first), and action buffers must stay untouched until then.  Steps that do not qualify (per-station
+ * debug outputs, discrete / random actions, a queue that needs the slow kernel, small batches) join and run as one
+ * launch.  halves = 1 (default): every call is ordered on the engine's stream. */
+int evc_set_pipeline(evc_engine* e, int32_t halves);
+/* The engine's stream waits for the pending half launches (no-op when there are none). */
+int evc_join(evc_engine* e);
+/* How many steps of this engine ran as two half launches so far, and (ordered, may be NULL) how many of those found
+ * work pending on the engine's stream and were ordered behind it with an event (diagnostics, tests). */
+int evc_pipelined_steps(evc_engine* e, uint64_t* count, uint64_t* ordered);
 
 /* Geometry queries. */
 int evc_obs_dim(const evc_engine* e);        /* F = 2n + k + 2 */
@@ -309,6 +328,9 @@ int evc_last_slow_count(evc_engine* e, int32_t* count);
  * step launched no slow kernel (projection off). */
 int evc_enable_timing(evc_engine* e, int32_t on);
 int evc_last_step_ms(evc_engine* e, float* ms_main, float* ms_slow);
+/* A pipelined step (evc_set_pipeline) is two launches: ms_main above is then the time from the first begin to the last end,
+ * and evc_last_half_ms gives each launch's own begin-to-end time (EVC_ESTATE if the last timed step was not pipelined). */
+int evc_last_half_ms(evc_engine* e, float* ms_first, float* ms_second);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SUSTAINGYM_AMD_LIB', os.path.join(_PKG, 'libevcharge_hip.so'))
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'evcharge.h')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_STATIONS, MAX_CONSTRAINTS, MAX_GROUPS, MAX_SESSIONS = 64, 32, 16, 256
 MOER_ROWS, MOER_COLS, EPISODE_STEPS = 289, 37, 288
 
@@ -66,6 +66,8 @@ SIGNATURES = {
     'evc_abi_version': (_i32, []),
     'evc_set_stream': (_i32, [_vp, _vp]),
     'evc_synchronize': (_i32, [_vp]),
+    'evc_set_pipeline': (_i32, [_vp, _i32]),
+    'evc_join': (_i32, [_vp]),
     'evc_obs_dim': (_i32, [_vp]),
     'evc_num_envs': (_i32, [_vp]),
     'evc_num_stations': (_i32, [_vp]),
@@ -97,6 +99,8 @@ SIGNATURES = {
     'evc_last_slow_count': (_i32, [_vp, C.POINTER(_i32)]),
     'evc_enable_timing': (_i32, [_vp, _i32]),
     'evc_last_step_ms': (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    'evc_last_half_ms': (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    'evc_pipelined_steps': (_i32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 
 class BatConfig(C.Structure):

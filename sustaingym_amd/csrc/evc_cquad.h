@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     const bool greedy = DBG && io.action_kind == EVC_ACTION_GREEDY;
     const bool stepwise = P.battery_stepwise != 0;
     const unsigned nquads = (N + 3u) >> 2;
-    EnvWalker walk((int)nquads, 4);
+    // this launch's share of the batch (StepIO::quad_lo / quad_hi; the whole batch unless the engine pipelines two halves)
+    const int q_lo = io.quad_hi > 0 ? io.quad_lo : 0;
+    EnvWalker walk(io.quad_hi > 0 ? io.quad_hi - io.quad_lo : (int)nquads, 4);
+    walk.first += q_lo;
+    walk.hi += q_lo;
     // The workgroup's quads {walk.first - wv + w + r * stride : w < 4, r} are shared by its four wavefronts: each takes
     // its own first one, then whichever comes next (an LDS counter).  A wavefront that ran into one of the rare
     // branches — exact rows, water-filling, a queue push: cold code and scratch reloads, 16 - 30 us per hit measured
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         S.local_count = 0;
         // the other control block still holds the PREVIOUS step's total (its launch is complete): report it to
         // the host (drain mode decision) and clear it for the next step
-        if (blockIdx.x == 0u) queue_begin_drain(P, P.slow_count_next[0]);
+        if (blockIdx.x == 0u && q_lo == 0) queue_begin_drain(P, P.slow_count_next[0]);   // one reporter per step: the launch that holds quad 0
     }
     if (tid < 64u) {
         const unsigned s = tid;

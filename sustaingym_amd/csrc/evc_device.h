@@ -137,6 +137,10 @@ struct StepIO {
     const void* actions;
     int action_kind, bins;
     evc_step_out out;
+    // quads [quad_lo, quad_hi) of the batch (a quad = 4 consecutive environments); quad_hi = 0: all of them.  The engine's
+    // pipelined mode steps the two halves of a batch as two launches on two streams (evc_set_pipeline); only the compact
+    // streaming kernels (evc_cquad.h) read these.
+    int quad_lo = 0, quad_hi = 0;
 };
 
 // ------------------------------------------------------------------------------------------

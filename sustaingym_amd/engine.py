@@ -68,6 +68,7 @@ class StepEngine:
                                   self.bank_slots, self.max_sessions, self.moer_days,
                                   C.byref(handle)), 'evc_create')
         self.handle = handle
+        self._pipeline = 1
         self._dev_out: dict[str, Any] | None = None
         self._host_out = None
         self._registered: list[np.ndarray] = []
@@ -239,6 +240,8 @@ class StepEngine:
         so = self._step_out_struct(out, lambda t: C.c_void_p(t.data_ptr()))
         check(self.lib.evc_step(self.handle, C.c_void_p(actions.data_ptr()), kind, bins, C.byref(so)),
               'evc_step')
+        if self._pipeline == 2:          # the returned tensors are consumed on the torch stream: order it after both halves
+            check(self.lib.evc_join(self.handle), 'evc_join')
         return out
 
     def make_stepper(self, bins: int = 0):
@@ -291,6 +294,8 @@ class StepEngine:
             ptr, ring = C.c_void_p(actions.data_ptr()), actions.shape[0]
         check(self.lib.evc_rollout(self.handle, ptr, kind, bins, int(steps), int(ring), C.byref(so)),
               'evc_rollout')
+        if self._pipeline == 2:
+            check(self.lib.evc_join(self.handle), 'evc_join')
         return out
 
     def set_policy_seed(self, seed: int, env_id_base: int = 0) -> None:
@@ -380,6 +385,17 @@ class StepEngine:
     def synchronize(self) -> None:
         check(self.lib.evc_synchronize(self.handle), 'evc_synchronize')
 
+    def set_pipeline(self, halves: int) -> None:
+        """``halves=2``: steps issued through ``make_stepper()`` run as two half-batch launches on two internal streams
+        whose tails overlap the other half's next launch (``evc_set_pipeline``, include/evcharge.h).  Their outputs are
+        complete on the torch stream only after ``join()``; ``step()`` / ``rollout()`` join by themselves."""
+        check(self.lib.evc_set_pipeline(self.handle, int(halves)), 'evc_set_pipeline')
+        self._pipeline = int(halves)
+
+    def join(self) -> None:
+        """Orders the engine's (torch) stream after the pending half launches of the pipelined mode."""
+        check(self.lib.evc_join(self.handle), 'evc_join')
+
     # ------------------------------------------------------------------ state access
     def env_scalars(self) -> dict[str, np.ndarray]:
         raw = np.zeros((self.N, 8), dtype=np.int32)
@@ -438,3 +454,16 @@ class StepEngine:
         a, b = C.c_float(), C.c_float()
         check(self.lib.evc_last_step_ms(self.handle, C.byref(a), C.byref(b)), 'evc_last_step_ms')
         return a.value, b.value
+
+    def last_half_ms(self) -> tuple[float, float]:
+        """Begin-to-end times of the two half launches of the last timed, pipelined step."""
+        a, b = C.c_float(), C.c_float()
+        check(self.lib.evc_last_half_ms(self.handle, C.byref(a), C.byref(b)), 'evc_last_half_ms')
+        return a.value, b.value
+
+    def pipelined_steps(self, ordered: bool = False):
+        """Steps that ran as two half launches; with ``ordered=True`` also how many of them had to wait for work pending
+        on the torch stream."""
+        c, f = C.c_uint64(), C.c_uint64()
+        check(self.lib.evc_pipelined_steps(self.handle, C.byref(c), C.byref(f)), 'evc_pipelined_steps')
+        return (c.value, f.value) if ordered else c.value

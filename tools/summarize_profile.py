@@ -70,8 +70,11 @@ def main(src: str, dst_prefix: str) -> None:
         k, e = max(cq, key=lambda ke: ke[1].get('dispatches_FETCH_SIZE', 0))
         tj = json.load(open(tpath))
         f, w = e['FETCH_SIZE_KB_mean'], e['WRITE_SIZE_KB_mean']
+        # pipelined halves (bench.py --pipeline 2, the default): a step is two launches of half the batch each
+        lps = 2 if 'half-batch' in str(out.get('bench_plain', {}).get('config', {}).get('pipeline', '')) else 1
         tj['caltech_N65536_project1_compact'] = {
-            'hbm_bytes_per_launch': int((1.4 * f + w) * 1024), 'fetch_kib': round(f, 1), 'write_kib': round(w, 1),
+            'hbm_bytes_per_launch': int((1.4 * f + w) * 1024), 'launches_per_step': lps,
+            'fetch_kib': round(f, 1), 'write_kib': round(w, 1),
             'fetch_factor': 1.4, 'hbm_bytes_per_launch_raw_counters': int((f + w) * 1024),
             'hbm_bytes_per_launch_guide_x2_rule': int((2 * f + w) * 1024), 'kernel': k,
             'code_object_sha256': out['code_object_sha256'],
