@@ -69,6 +69,9 @@ def parse_args(argv=None):
                    help='2 (default): the batch stepped as two half-batch launches on two streams whose tails overlap the '
                         "next launches (evc_set_pipeline; the action ring is resident, nothing reads an output between steps); "
                         '1: one launch per step, every step ordered on one stream')
+    p.add_argument('--no-single-launch', action='store_true',
+                   help='skip the one-launch-per-step comparison leg of a pipelined run (profiling passes: keeps every dispatch '
+                        'of the streaming kernel a half launch)')
     p.add_argument('--phase', default='stagger', choices=['stagger', 'sync'],
                    help="'stagger' (default): episode phases spread uniformly over the day, every step costs the "
                         "day's average; 'sync': all episodes start together")
@@ -810,7 +813,7 @@ def main():
         timed = w.time_kernels(args.kernel_timing_steps)
         roofline = roofline_record(w, timed, algorithmic_bytes_per_env_step(n, k))
         roofline['launch_overhead_ms'] = round(elapsed / args.steps * 1e3 - roofline.get('step_period_ms', roofline['avg_kernel_ms']), 5)
-        if w.pipeline == 2:
+        if w.pipeline == 2 and not args.no_single_launch:
             # the same workload as ONE launch per step (evc_set_pipeline(1)), for continuity with rounds 1-2
             w.eng.set_pipeline(1)
             w.run(32)

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         S.local_count = 0;
         // the other control block still holds the PREVIOUS step's total (its launch is complete): report it to
         // the host (drain mode decision) and clear it for the next step
-        if (blockIdx.x == 0u && q_lo == 0) queue_begin_drain(P, P.slow_count_next[0]);   // one reporter per step: the launch that holds quad 0
+        if (blockIdx.x == 0u) queue_begin_drain(P, P.slow_count_next[0]);               // (a half launch of the pipelined mode has control blocks of its own)
     }
     if (tid < 64u) {
         const unsigned s = tid;

@@ -78,7 +78,7 @@ struct evc_engine {
     double* d_moer_hist = nullptr;
     float* d_moer_obs = nullptr;
     NetTables* d_tables = nullptr;
-    int* d_slow_count = nullptr;  // [2]: queue length per step parity
+    int* d_slow_count = nullptr;  // [2 halves][2]: queue length per step parity (second pair: the second half launch of the pipelined mode); [4..5]: always zero, for the warm-up launches
     int* d_slow_list = nullptr;
     unsigned long long* d_tie = nullptr;   // Params::tie_counters
     // Drain mode (who solves what the streaming kernel queues): on a workload whose steps queue at most a few
@@ -88,7 +88,7 @@ struct evc_engine {
     // serialise — the slow kernel runs (one workgroup per queued environment).  The decision reads the per-step
     // totals the kernels report into a page-locked ring of one day: stale by however far the host runs ahead,
     // which only costs speed, never correctness — either drainer finishes every queued step.
-    int* h_qlen = nullptr;        // [kQlenRing] host view
+    int* h_qlen = nullptr;        // [2 halves][kQlenRing] host view (a step that is one launch reports in the first ring, the host zeroes its slot of the second)
     int* d_qlen = nullptr;        // device address of the same memory
     unsigned long long step_index = 0;
     bool warmed = false;          // both lean streaming copies have been launched once
@@ -122,7 +122,7 @@ struct evc_engine {
     int pipeline = 1;
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
-    bool halves_pending = false, side_warmed = false;
+    bool halves_pending = false, side_warmed = false, last_split = false;
     unsigned long long split_steps = 0;   // steps that ran as two half launches (evc_pipelined_steps) ...
     unsigned long long fork_steps = 0;    // ... and how many of them had to be ordered behind pending work of the engine's stream
     // host mirrors
@@ -415,7 +415,12 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         // the GPU by many steps: a rule that followed the last few reports switched too late on a day whose
         // queues ramp up within a few periods — 107 instead of 78 us per step on JPL's GMM days, measured)
         int recent = 0;
-        for (int i = 0; i < kQlenRing; i++) { const int v = ((volatile int*)e->h_qlen)[i]; if (v > recent) recent = v; }
+        const volatile int* ring = (volatile int*)e->h_qlen;
+        auto reported = [&](int i) {                 // a step's queue = what its launch(es) reported (two rings: two half launches)
+            const int a = ring[i], b = ring[kQlenRing + i];
+            return (a == INT_MAX || b == INT_MAX) ? INT_MAX : a + b;
+        };
+        for (int i = 0; i < kQlenRing; i++) { const int v = reported(i); if (v > recent) recent = v; }
         drain = recent <= e->drain_max_queue;
         if (!drain && recent != INT_MAX) {
             // A day with a congested part.  The ring is indexed by the period of the day, so the slots around this step's hold
@@ -425,7 +430,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             int around = 0;
             const int here = (int)(e->step_index % kQlenRing);
             for (int d = -kDrainLookBack; d <= kDrainLookAhead; d++) {
-                const int v = ((volatile int*)e->h_qlen)[(here + d + kQlenRing) % kQlenRing];
+                const int v = reported((here + d + kQlenRing) % kQlenRing);
                 if (v > around) around = v;
             }
             drain = around <= e->drain_max_queue;
@@ -441,11 +446,19 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     // in the kernel, or no projection), on actions read straight from the caller's buffer (the discretised / random forms
     // go through one staging buffer the next step would overwrite), and only where a half still fills the grid.
     const int split_cap = e->P.project ? e->proj_grid : e->quad_grid;
-    const bool split = e->pipeline == 2 && e->use_quad && e->compact && !dbg && (mode == 1 || !e->P.project) &&
+    const bool split = e->pipeline == 2 && e->use_quad && e->compact && !dbg &&
                        action_kind == EVC_ACTION_F32 && ((e->P.N + 3) / 4) / 2 >= 4 * split_cap;
+    // The queue's control blocks and report rings exist once per half launch.  A step that is ONE launch uses the first set;
+    // where the form changes, what the other form left behind is cleared (rare: a mode or action-kind change).
+    if (split != e->last_split) {
+        if (int rc = join_halves(e)) return rc;
+        (void)hipMemsetAsync(e->d_slow_count, 0, 4 * sizeof(int), e->stream);
+        e->last_split = split;
+    }
+    if (!split && e->h_qlen) ((volatile int*)e->h_qlen)[kQlenRing + (e->step_index % kQlenRing)] = 0;
     if (!split)
         if (int rc = join_halves(e)) return rc;
-    auto launch_split = [&](auto kernel) {
+    auto launch_split = [&](auto kernel, auto slow_kernel, bool with_slow) {
         // Both halves wait for whatever the engine's stream still holds (the caller's actions): one event, recorded there and
         // waited for by both side streams — but only if the stream holds anything.  An idle stream (actions staged earlier,
         // a replay, a caller that synchronises by itself) needs no ordering, and the event costs: 11 us of host time per
@@ -458,14 +471,27 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             StepIO ioh = io;
             ioh.quad_lo = h ? mid : 0;
             ioh.quad_hi = h ? nq : mid;
+            // the half's own queue: control blocks, its stretch of the list (a half queues at most its own environments), report ring
+            Params Ph = e->P;
+            Ph.slow_count = e->P.slow_count + 2 * h;
+            Ph.slow_count_next = e->P.slow_count_next + 2 * h;
+            Ph.slow_list = e->P.slow_list + (h ? mid * 4 : 0);
+            Ph.host_qlen = e->P.host_qlen ? e->P.host_qlen + h * kQlenRing : nullptr;
             int grid = (ioh.quad_hi - ioh.quad_lo + 3) / 4;
             if (grid > split_cap) grid = split_cap;
             if (grid >= 8) grid -= grid % 8;
             if (fork) (void)hipStreamWaitEvent(e->side[h], e->fork_ev, 0);
             if (e->timing)
-                hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, e->side[h], e->ev[h ? 4 : 0], e->ev[h ? 5 : 1], 0, e->P, ioh);
+                hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, e->side[h], e->ev[h ? 4 : 0], e->ev[h ? 5 : 1], 0, Ph, ioh);
             else
-                hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, e->side[h], e->P, ioh);
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, e->side[h], Ph, ioh);
+            if (with_slow) {
+                // the slow kernel of this half right behind it on the same stream: it runs under the other half's streaming kernel
+                if (e->timing && h == 0)
+                    hipExtLaunchKernelGGL(slow_kernel, dim3(e->solver_grid), dim3(256), 0, e->side[h], e->ev[2], e->ev[3], 0, Ph, ioh);
+                else
+                    hipLaunchKernelGGL(slow_kernel, dim3(e->solver_grid), dim3(256), 0, e->side[h], Ph, ioh);
+            }
         }
         (void)hipGetLastError();                 // hipStreamQuery's hipErrorNotReady is not an error
         e->halves_pending = true;
@@ -491,6 +517,8 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                    first launch (code load, scratch sizing: milliseconds) lands in a later mode switch */      \
                 Params pw = e->P;                                                                  \
                 pw.N = 0;                                                                          \
+                pw.slow_count = e->d_slow_count + 4;                                               \
+                pw.slow_count_next = e->d_slow_count + 5;                                          \
                 pw.host_qlen = nullptr;                                                            \
                 hipLaunchKernelGGL(KDRAIN, dim3(LEANGRID), dim3(256), 0, e->stream, pw, io);       \
                 hipLaunchKernelGGL(KFAST, dim3(LEANGRID), dim3(256), 0, e->stream, pw, io);        \
@@ -500,18 +528,24 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 /* a stream's hardware queue sizes its scratch at the first launch that needs it (milliseconds) */ \
                 Params pw = e->P;                                                                  \
                 pw.N = 0;                                                                          \
+                pw.slow_count = e->d_slow_count + 4;                                               \
+                pw.slow_count_next = e->d_slow_count + 5;                                          \
                 pw.host_qlen = nullptr;                                                            \
                 StepIO iow = io;                                                                   \
                 iow.quad_lo = iow.quad_hi = 8;                                                     \
-                for (int h = 0; h < 2; h++)                                                        \
+                for (int h = 0; h < 2; h++) {                                                      \
                     hipLaunchKernelGGL(KDRAIN, dim3(LEANGRID), dim3(256), 0, e->side[h], pw, iow); \
+                    hipLaunchKernelGGL(KFAST, dim3(LEANGRID), dim3(256), 0, e->side[h], pw, iow);  \
+                    hipLaunchKernelGGL(solver_step_kernel<W>, dim3(8), dim3(256), 0, e->side[h], pw, iow); \
+                }                                                                                  \
                 e->side_warmed = true;                                                             \
             }                                                                                      \
             if (dbg) launch(KDBG, GRID, 256, 0);                                                   \
-            else if (split) launch_split(KDRAIN);                                                  \
+            else if (split && mode == 1) launch_split(KDRAIN, solver_step_kernel<W>, false);       \
+            else if (split) { launch_split(KFAST, solver_step_kernel<W>, true); solver_ran = true; } \
             else if (mode == 1) launch(KDRAIN, LEANGRID, 256, 0);                                  \
             else launch(KFAST, LEANGRID, 256, 0);                                                  \
-            if (mode == 0) {                                                                       \
+            if (mode == 0 && !split) {                                                             \
                 launch(solver_step_kernel<W>, e->solver_grid, 256, 1);                              \
                 solver_ran = true;                                                                 \
             }                                                                                      \
@@ -519,13 +553,15 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             if (!e->side_warmed) {                                                                 \
                 Params pw = e->P;                                                                  \
                 pw.N = 0;                                                                          \
+                pw.slow_count = e->d_slow_count + 4;                                               \
+                pw.slow_count_next = e->d_slow_count + 5;                                          \
                 StepIO iow = io;                                                                   \
                 iow.quad_lo = iow.quad_hi = 8;                                                     \
                 for (int h = 0; h < 2; h++)                                                        \
                     hipLaunchKernelGGL(KPLAIN, dim3(GRID), dim3(256), 0, e->side[h], pw, iow);     \
                 e->side_warmed = true;                                                             \
             }                                                                                      \
-            launch_split(KPLAIN);                                                                  \
+            launch_split(KPLAIN, solver_step_kernel<W>, false);                                    \
         } else {                                                                                   \
             launch(KPLAIN, GRID, 256, 0);                                                          \
         }                                                                                          \
@@ -711,7 +747,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(dmalloc(&e->d_nsess, (size_t)bank_slots));
     A(dmalloc(&e->d_slot_moer, (size_t)bank_slots));
     A(dmalloc(&e->d_maxprofit, (size_t)bank_slots));
-    A(dmalloc(&e->d_slow_count, 2));
+    A(dmalloc(&e->d_slow_count, 6));
     A(dmalloc(&e->d_slow_list, N));
     A(dmalloc(&e->d_tie, 2 * kTieSlots));
     A(dmalloc(&e->d_idbuf, 2 * N));
@@ -732,7 +768,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(hipMemset(e->d_maxprofit, 0, sizeof(double) * (size_t)bank_slots));
     A(hipMemset(e->d_moer_hist, 0, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS));
     A(hipMemset(e->d_moer_obs, 0, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
-    A(hipMemset(e->d_slow_count, 0, 2 * sizeof(int)));
+    A(hipMemset(e->d_slow_count, 0, 6 * sizeof(int)));
     A(hipMemset(e->d_tie, 0, 2 * kTieSlots * sizeof(unsigned long long)));
     A(hipMemset(e->d_slow_list, 0xff, sizeof(int) * N));
     A(copy_h2d(e->d_tables, &T, sizeof(T), e->stream));
@@ -777,8 +813,8 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     }
     compute_grids(e);
     // queue lengths reported to the host (drain mode); without it the slow kernel simply always runs
-    if (hipHostMalloc((void**)&e->h_qlen, sizeof(int) * kQlenRing, hipHostMallocMapped) == hipSuccess) {
-        for (int i = 0; i < kQlenRing; i++) e->h_qlen[i] = INT_MAX;
+    if (hipHostMalloc((void**)&e->h_qlen, sizeof(int) * 2 * kQlenRing, hipHostMallocMapped) == hipSuccess) {
+        for (int i = 0; i < kQlenRing; i++) { e->h_qlen[i] = INT_MAX; e->h_qlen[kQlenRing + i] = 0; }
         if (hipHostGetDevicePointer((void**)&e->d_qlen, e->h_qlen, 0) != hipSuccess) e->d_qlen = nullptr;
     } else {
         e->h_qlen = nullptr;
@@ -1300,11 +1336,11 @@ int evc_last_slow_count(evc_engine* e, int32_t* count) {
     if (!e || !count) return fail(EVC_EINVAL, "null argument");
     if (int rc = bind(e)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    int both[2];
-    HIP_TRY(copy_d2h(both, e->d_slow_count, 2 * sizeof(int), e->stream));
+    int both[4];
+    HIP_TRY(copy_d2h(both, e->d_slow_count, 4 * sizeof(int), e->stream));
     // the control block of the most recent step is cleared by the drainer of the NEXT step; the one not
-    // selected for the next step holds the last count
-    *count = both[(e->step_parity + 1) & 1];
+    // selected for the next step holds the last count (second pair: the second half launch of a pipelined step)
+    *count = both[(e->step_parity + 1) & 1] + (e->last_split ? both[2 + ((e->step_parity + 1) & 1)] : 0);
     return EVC_OK;
 }
 

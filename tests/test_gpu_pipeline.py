@@ -34,11 +34,17 @@ def _assert_same(a, b, tag):
         assert np.array_equal(a[k], b[k]), (tag, k, np.argwhere(np.asarray(a[k]) != np.asarray(b[k]))[:4])
 
 
-@pytest.mark.parametrize('site,project,busy', [('caltech', True, False), ('jpl', True, True), ('caltech', False, False)])
-def test_pipelined_halves_equal_the_single_launch(site, project, busy, monkeypatch):
+@pytest.mark.parametrize('site,project,busy,drain', [
+    ('caltech', True, False, '1'),        # queue drained inside the half launches (the default only after a day of short queues)
+    ('jpl', True, True, '1'),             # ... many queued environments per workgroup
+    ('jpl', True, True, '0'),             # the slow kernel: each half has its own queue and its own slow launch behind it
+    ('caltech', True, True, 'auto'),      # the engine's own choice, changing over the run
+    ('caltech', False, False, '1'),       # no projection: no queue at all
+])
+def test_pipelined_halves_equal_the_single_launch(site, project, busy, drain, monkeypatch):
     import torch
     from sustaingym_amd.network import site_str_to_site
-    monkeypatch.setenv('EVC_DRAIN', '1')          # queue drained in the kernel from the first step on (the default waits a day)
+    monkeypatch.setenv('EVC_DRAIN', drain)
     net = site_str_to_site(site)
     n = net.num_stations
     wl = make_workload(net, N, bank_slots=1024, seed=5, busy=busy, moer_days=4)
@@ -63,6 +69,7 @@ def test_pipelined_halves_equal_the_single_launch(site, project, busy, monkeypat
     m1, m2 = one.read_metrics(), two.read_metrics()
     for k in m1:                                         # sums over the batch by float atomics: equal up to their order
         np.testing.assert_allclose(m1[k], m2[k], rtol=1e-12, err_msg=k)
+    assert one.last_slow_count() == two.last_slow_count()          # the halves' queues add up to the single launch's
 
     # entry points in between join by themselves: a debug step (one launch), a partial reset, pipelined steps again, the
     # synchronous step() API (joins before it returns its tensors)

@@ -13,11 +13,11 @@ mkdir -p $OUT
 python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
-    python $REPO/bench.py --steps 288 --warmup 96 --no-cpu-baseline --no-secondary > $OUT/bench_traced.json 2> $OUT/trace.err
+    python $REPO/bench.py --steps 288 --warmup 96 --no-cpu-baseline --no-secondary --no-single-launch --kernel-timing-steps 1 > $OUT/bench_traced.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- \
-    python $REPO/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-secondary --kernel-timing-steps 1 > /dev/null 2> $OUT/pmc_fetch.err
+    python $REPO/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-secondary --no-single-launch --kernel-timing-steps 1 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- \
-    python $REPO/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-secondary --kernel-timing-steps 1 > /dev/null 2> $OUT/pmc_write.err
+    python $REPO/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-secondary --no-single-launch --kernel-timing-steps 1 > /dev/null 2> $OUT/pmc_write.err
 cd $REPO
 python tools/summarize_profile.py $OUT $REPO/gpurun_out/${TAG}
 cat $OUT/bench_plain.json
