@@ -447,7 +447,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     // go through one staging buffer the next step would overwrite), and only where a half still fills the grid.
     const int split_cap = e->P.project ? e->proj_grid : e->quad_grid;
     const bool split = e->pipeline == 2 && e->use_quad && e->compact && !dbg &&
-                       action_kind == EVC_ACTION_F32 && ((e->P.N + 3) / 4) / 2 >= 4 * split_cap;
+                       action_kind == EVC_ACTION_F32 && ((e->P.N + 3) / 4) / 2 >= (getenv("EVC_SPLIT_MINQ") ? atoi(getenv("EVC_SPLIT_MINQ")) : 4) * split_cap;
     // The queue's control blocks and report rings exist once per half launch.  A step that is ONE launch uses the first set;
     // where the form changes, what the other form left behind is cleared (rare: a mode or action-kind change).
     if (split != e->last_split) {
