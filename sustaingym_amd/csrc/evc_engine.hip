@@ -58,6 +58,7 @@ constexpr int kQlenRing = 288;           // one report per period of a day
 #define EVC_PROJ_WAVES 3                // wavefronts per SIMD the PROJECTING lean compact kernels are held to (evc_cquad.h, WAVES)
 #endif
 constexpr int kDrainLookBack = 12, kDrainLookAhead = 36;   // periods of the day around the current one whose reports decide the step's mode
+constexpr int kPipeSkewUs = 12;            // start skew of the second half of a pipelined step train (launch_split)
 constexpr int kDrainMaxQueueDefault = 16;   // in-kernel drain only while NO step of the last day queued more than this (EVC_DRAIN_MAXQ overrides)
 
 struct evc_engine {
@@ -139,6 +140,12 @@ struct evc_engine {
 namespace {
 
 __global__ void side_stream_warmup_kernel() {}
+
+// one wavefront that does nothing for `ticks` of the 100 MHz constant clock (launch_split: start skew of the second half)
+__global__ void skew_kernel(unsigned ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 
 // the engine's stream waits for the two half launches of the pipelined mode (no-op otherwise)
 int join_halves(evc_engine* e) {
@@ -467,6 +474,12 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         static const int fork_mode = getenv("EVC_PIPE_FORK") ? atoi(getenv("EVC_PIPE_FORK")) : -1;   // measurements: 0 never, 1 always
         const bool fork = fork_mode >= 0 ? fork_mode != 0 : hipStreamQuery(e->stream) != hipSuccess;
         if (fork) (void)hipEventRecord(e->fork_ev, e->stream);
+        // Cold start (nothing pending: the first pipelined step, or the first after a join): two launches that begin together
+        // share the GPU evenly, end together and leave their tails side by side — the lock-step the mode exists to avoid, and it
+        // only drifts apart over hundreds of steps (24.2 us per step over the first 600, 22.6 after).  The second half therefore
+        // starts its train half a launch late.
+        static const int skew_us = getenv("EVC_PIPE_SKEW_US") ? atoi(getenv("EVC_PIPE_SKEW_US")) : kPipeSkewUs;
+        const bool cold = !e->halves_pending;
         for (int h = 0; h < 2; h++) {
             StepIO ioh = io;
             ioh.quad_lo = h ? mid : 0;
@@ -481,6 +494,8 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             if (grid > split_cap) grid = split_cap;
             if (grid >= 8) grid -= grid % 8;
             if (fork) (void)hipStreamWaitEvent(e->side[h], e->fork_ev, 0);
+            if (cold && h == 1 && skew_us > 0 && !e->timing)
+                hipLaunchKernelGGL(skew_kernel, dim3(1), dim3(64), 0, e->side[h], (unsigned)skew_us * 100u);
             if (e->timing)
                 hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, e->side[h], e->ev[h ? 4 : 0], e->ev[h ? 5 : 1], 0, Ph, ioh);
             else

@@ -61,3 +61,30 @@ def test_battery_device_tensors_and_full_size_invariants():
     o, r, d = env2.step(b)
     assert np.array_equal(o[0], o[1]) and np.array_equal(o[0], o[3]) and r[0] == r[1] == r[3]
     env.close(); env2.close()
+
+
+def test_battery_lean_stepper_equals_step():
+    """make_stepper() (bound pointers, no per-call checks: what bench.py times) and step() are the same launch."""
+    import torch
+    from sustaingym_amd.battery import BatteryDispatchVectorEnv, synthetic_market_traces
+    N, k = 4096, 36
+    tr = synthetic_market_traces(256, k, seed=8)
+    envs = []
+    for _ in range(2):
+        env = BatteryDispatchVectorEnv(N, k, bank_slots=256, output='torch')
+        env.upload_traces(tr)
+        env.reset(np.arange(N) % 256)
+        envs.append(env)
+    step, (obs2, rew2, term2) = envs[1].make_stepper()
+    assert term2.dtype == torch.bool
+    g = torch.Generator(device='cuda'); g.manual_seed(4)
+    for t in range(290):                                         # across the end of the day
+        bids = (torch.rand((N, 2 * k), device='cuda', generator=g) * 90).contiguous()
+        obs1, rew1, term1 = envs[0].step(bids)
+        step(bids.data_ptr())
+        if t % 48 == 0 or t >= 286:
+            torch.cuda.synchronize()
+            assert torch.equal(obs1, obs2) and torch.equal(rew1, rew2) and torch.equal(term1, term2), t
+    assert envs[0].read_metrics() == envs[1].read_metrics()
+    for env in envs:
+        env.close()
