@@ -58,7 +58,7 @@ constexpr int kQlenRing = 288;           // one report per period of a day
 #define EVC_PROJ_WAVES 3                // wavefronts per SIMD the PROJECTING lean compact kernels are held to (evc_cquad.h, WAVES)
 #endif
 constexpr int kDrainLookBack = 12, kDrainLookAhead = 36;   // periods of the day around the current one whose reports decide the step's mode
-constexpr int kPipeSkewUs = 12;            // start skew of the second half of a pipelined step train (launch_split)
+constexpr int kPipeSkewUs = 0;             // start skew (us) of the second half of a pipelined step train (launch_split): measured, no gain
 constexpr int kDrainMaxQueueDefault = 16;   // in-kernel drain only while NO step of the last day queued more than this (EVC_DRAIN_MAXQ overrides)
 
 struct evc_engine {
@@ -475,9 +475,10 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         const bool fork = fork_mode >= 0 ? fork_mode != 0 : hipStreamQuery(e->stream) != hipSuccess;
         if (fork) (void)hipEventRecord(e->fork_ev, e->stream);
         // Cold start (nothing pending: the first pipelined step, or the first after a join): two launches that begin together
-        // share the GPU evenly, end together and leave their tails side by side — the lock-step the mode exists to avoid, and it
-        // only drifts apart over hundreds of steps (24.2 us per step over the first 600, 22.6 after).  The second half therefore
-        // starts its train half a launch late.
+        // share the GPU evenly and end together, tails side by side; the trains drift apart over the next steps.  Starting
+        // the second half's train late by half a launch (EVC_PIPE_SKEW_US) was measured: the driver's 20-step window gains
+        // 1 us per step in the median and loses the skew itself, and the steady-state period is WORSE (24.4 against 23.4 us:
+        // the phase the trains settle into by themselves is better than the one imposed).  Off by default.
         static const int skew_us = getenv("EVC_PIPE_SKEW_US") ? atoi(getenv("EVC_PIPE_SKEW_US")) : kPipeSkewUs;
         const bool cold = !e->halves_pending;
         for (int h = 0; h < 2; h++) {

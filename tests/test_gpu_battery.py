@@ -85,6 +85,8 @@ def test_battery_lean_stepper_equals_step():
         if t % 48 == 0 or t >= 286:
             torch.cuda.synchronize()
             assert torch.equal(obs1, obs2) and torch.equal(rew1, rew2) and torch.equal(term1, term2), t
-    assert envs[0].read_metrics() == envs[1].read_metrics()
+    m0, m1 = envs[0].read_metrics(), envs[1].read_metrics()
+    for key in m0:                                               # batch sums by float atomics: equal up to their order
+        np.testing.assert_allclose(m0[key], m1[key], rtol=1e-12, err_msg=key)
     for env in envs:
         env.close()
