@@ -778,8 +778,7 @@ def main():
     pipelined0 = w.eng.pipelined_steps()
     t0 = time.perf_counter()
     w.run(args.steps)
-    w.eng.join()                 # the engine's stream waits for both half launches; barrier() then drains the device
-    barrier()
+    barrier()                    # torch.cuda.synchronize drains the whole device, the side streams of the pipelined mode included
     local_elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(local_elapsed, coll_dev)
     timed_env_steps = w.eng.read_metrics()['env_steps'] - steps0
