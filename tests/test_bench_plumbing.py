@@ -31,9 +31,28 @@ def test_traffic_is_refused_when_measured_on_other_kernels(tmp_path, monkeypatch
     assert bench.lookup_traffic('caltech', 65536, True, 'compact') == (123, 's')
 
 
+def test_traffic_is_per_step_and_tied_to_the_launch_form(tmp_path, monkeypatch):
+    """A pipelined step (bench.py --pipeline 2) is two launches: the entry holds bytes per launch and how many launches make a
+    step; the figure is refused for the other form."""
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    (prof / 'traffic.json').write_text(json.dumps({'caltech_N65536_project1_compact': {
+        'hbm_bytes_per_launch': 100, 'launches_per_step': 2, 'source': 's', 'code_object_sha256': bench.code_object_hash()}}))
+    assert bench.lookup_traffic('caltech', 65536, True, 'compact', 2) == (200, 's')
+    val, why = bench.lookup_traffic('caltech', 65536, True, 'compact', 1)
+    assert val is None and '2 launch(es) per step' in why
+
+
 def test_committed_traffic_entry_matches_or_is_refused():
-    val, why = bench.lookup_traffic('caltech', 65536, True, 'compact')
+    val, why = bench.lookup_traffic('caltech', 65536, True, 'compact', 2)
     assert val is None or (isinstance(val, int) and val > 5e7)
+
+
+def test_pipeline_arguments():
+    a = bench.parse_args([])
+    assert a.pipeline == 2 and not a.no_single_launch
+    assert bench.parse_args(['--pipeline', '1', '--no-single-launch']).pipeline == 1
 
 
 def test_argument_surface():
