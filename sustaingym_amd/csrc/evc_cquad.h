@@ -275,6 +275,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         bool live = ev && !after_done;
         const int t1 = t + 1;
         const bool more = __ballot(A > 16u) != 0ull;            // wave-uniform: entry slots 1..3 in use
+#ifdef EVC_PREFETCH_EARLY          /* measurement builds: the next quad's rows requested at the top of the iteration */
+        quad_next = take_quad();
+        if (quad_next >= 0) nxt = issue(quad_next);
+#endif
         // The rest of the iteration is instantiated for NS = 1..4 entry slots per lane: the widest row of
         // the wave decides (NS = 1: every row has <= 16 entries, the normal case of a quiet network;
         // midday on a real Caltech / JPL day needs 2-3).  Registers — and spills, all of them in the
@@ -579,8 +583,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // prefetch of the next quad's rows: issued here, after the charge / event section (its 15 VGPRs are not alive through
         // the register-hungry part of the iteration: 184 -> 155 spilled VGPRs, -0.7 us per step with synchronised phases);
         // nothing to fetch after the last quad
+#ifndef EVC_PREFETCH_EARLY
         quad_next = take_quad();
         if (quad_next >= 0) nxt = issue(quad_next);
+#endif
         // ---- observation image: demands / est_departures of the surviving entries ----
         auto scatter_obs = [&](int c) {
             if (live && alive[c]) {
