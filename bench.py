@@ -441,8 +441,9 @@ def secondary_rollout(policy, dev_index, battery, episodes='synthetic') -> dict:
     def episodes_per_call(fused, reps):
         os.environ['EVC_ROLLOUT_FUSED'] = '1' if fused else '0'
         try:
-            eng.rollout(policy=policy, steps=EPISODE)                  # untimed (first launch, bank wrap)
-            torch.cuda.synchronize(dev)
+            for _ in range(8 if fused else 1):                         # untimed: first launches, bank wrap, and — synchronised calls,
+                eng.rollout(policy=policy, steps=EPISODE)              # like an evaluation loop's — what the engine needs to pick the
+                torch.cuda.synchronize(dev)                            # faster register budget of the kernel (evc_last_rollout_waves)
             t0 = time.perf_counter()
             for _ in range(reps):
                 eng.rollout(policy=policy, steps=EPISODE)
@@ -451,6 +452,7 @@ def secondary_rollout(policy, dev_index, battery, episodes='synthetic') -> dict:
         finally:
             os.environ.pop('EVC_ROLLOUT_FUSED', None)
     fused = episodes_per_call(True, 5)
+    waves_chosen = eng.last_rollout_waves()
     eng.enable_timing(True)
     eng.rollout(policy=policy, steps=EPISODE)
     kernel_ms = eng.last_step_ms()[0]
@@ -484,7 +486,7 @@ def secondary_rollout(policy, dev_index, battery, episodes='synthetic') -> dict:
                         f'projection on, {policy} policy on the device, whole episodes (288 periods), autoreset',
             'env_steps_per_s': round(N * EPISODE / fused, 1), 'episode_ms': round(fused * 1e3, 4),
             'us_per_period': round(fused / EPISODE * 1e6, 3), 'launches_per_episode': 1,
-            'kernel': 'evc::rollout_kernel', 'kernel_ms': round(kernel_ms, 4), 'roofline': roof,
+            'kernel': 'evc::rollout_kernel', 'kernel_ms': round(kernel_ms, 4), 'waves_per_simd_chosen': waves_chosen, 'roofline': roof,
             'loop_of_steps': {'env_steps_per_s': round(N * EPISODE / loop, 1), 'episode_ms': round(loop * 1e3, 3),
                               'launches_per_episode': EPISODE * (2 if policy == 'random' else 1) + 0,
                               'note': 'EVC_ROLLOUT_FUSED=0: evc_step per period (random: + the action kernel), observations written every period'},

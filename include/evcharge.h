@@ -256,6 +256,11 @@ int evc_step(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_
 int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int32_t bins,
                 int32_t steps, int32_t ring_len, const evc_step_out* out);
 
+/* Diagnostics: the register budget (2 or 3 wavefronts per SIMD) the last fused evc_rollout launch ran with; 0 if none has.
+ * The projecting rollout kernels exist at both and the engine keeps the one that is faster on the caller's workload (it times
+ * its own launches; EVC_ROLLOUT_WAVES=2|3 fixes the choice). */
+int evc_last_rollout_waves(evc_engine* e, int32_t* waves);
+
 /* Seeds the device-resident random policy (EVC_ACTION_RANDOM).  The action of station s of environment
  * e in period t of its episode number p is a pure function of (seed, env_id_base + e, p, t, s):
  * Philox4x32-10, key = seed, counter = (t | (s/4) << 16, p, env_id_base + e, 0x504f4c43), word s%4;

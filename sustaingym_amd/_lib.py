@@ -82,6 +82,7 @@ SIGNATURES = {
     'evc_step': (_i32, [_vp, _vp, _i32, _i32, C.POINTER(StepOut)]),
     'evc_rollout': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(StepOut)]),
     'evc_set_policy_seed': (_i32, [_vp, C.c_uint64, _u32]),
+    'evc_last_rollout_waves': (_i32, [_vp, C.POINTER(_i32)]),
     'evc_fill_random_actions': (_i32, [_vp, _i32, _vp]),
     'evc_gather_agent_obs': (_i32, [_vp, _vp, _vp, _vp]),
     'evc_host_register': (_i32, [_vp, C.c_size_t]),

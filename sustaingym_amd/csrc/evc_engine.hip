@@ -126,6 +126,16 @@ struct evc_engine {
     bool halves_pending = false, side_warmed = false, last_split = false;
     unsigned long long split_steps = 0;   // steps that ran as two half launches (evc_pipelined_steps) ...
     unsigned long long fork_steps = 0;    // ... and how many of them had to be ordered behind pending work of the engine's stream
+    // fused rollout: which register budget of the projecting kernels is faster on the caller's workload (launch_rollout)
+    struct RolloutTuner {
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        int pending = -1;                 // setting (2 | 3) of the launch whose events are outstanding
+        double pending_work = 0.0;        // its environment-steps
+        double best[2] = {0.0, 0.0};      // ms per environment-step: [0] two, [1] three wavefronts per SIMD
+        int count[2] = {0, 0};
+        unsigned launches = 0;
+    } roll;
+    int last_rollout_waves = 0;
     // host mirrors
     unsigned long long env_steps = 0;
     int step_parity = 0;
@@ -178,6 +188,8 @@ void free_all(evc_engine* e) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->roll.ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
     for (int h = 0; h < 2; h++) {
@@ -649,8 +661,43 @@ int launch_rollout(evc_engine* e, const void* actions_dev, int ring_len, int act
     io.seed = e->policy_seed;
     io.out = *out;
     const int grid = (((e->P.N + 3) / 4) + 3) / 4;          // one quad of environments per wavefront
-    if (!launch_rollout_kernel(e->P, io, grid, e->stream, e->timing ? e->ev[0] : nullptr, e->timing ? e->ev[1] : nullptr))
+    // Register budget of the projecting kernels (rollout_kernel's WAVES, evc_rollout.h): which of 2 / 3 wavefronts per SIMD
+    // is faster depends on how often the caller's days visit the projection branch, so the engine measures — every launch
+    // carries its own begin / end events, the previous launch's duration per environment-step is read when this one is
+    // issued (only if it has finished: never a wait), each setting is tried until it has two readings, then the faster one
+    // is used and the other re-tried every 64th launch.  EVC_ROLLOUT_WAVES=2|3 fixes the setting.
+    evc_engine::RolloutTuner& T = e->roll;
+    if (T.pending >= 0 && hipEventQuery(T.ev[1]) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, T.ev[0], T.ev[1]) == hipSuccess && T.pending_work > 0.0) {
+            const double per = (double)ms / T.pending_work;
+            double& best = T.best[T.pending - 2];
+            if (T.count[T.pending - 2]++ > 0) best = best > 0.0 && best < per ? best : per;     // the first reading of a setting includes its code load
+        }
+        T.pending = -1;
+    }
+    (void)hipGetLastError();
+    int waves = 3;
+    if (e->P.project) {
+        static const int forced = getenv("EVC_ROLLOUT_WAVES") ? atoi(getenv("EVC_ROLLOUT_WAVES")) : 0;
+        if (forced == 2 || forced == 3) waves = forced;
+        else if (T.count[1] < 3) waves = 3;
+        else if (T.count[0] < 3) waves = 2;
+        else {
+            waves = T.best[0] < T.best[1] ? 2 : 3;
+            if (++T.launches % 64 == 0) waves = 5 - waves;                                  // conditions change: look at the other one again
+        }
+    }
+    hipEvent_t ev0 = e->timing ? e->ev[0] : nullptr, ev1 = e->timing ? e->ev[1] : nullptr;
+    if (!e->timing && e->P.project && T.pending < 0 && T.ev[0]) {
+        ev0 = T.ev[0];
+        ev1 = T.ev[1];
+        T.pending = waves;
+        T.pending_work = (double)e->P.N * (double)steps;
+    }
+    if (!launch_rollout_kernel(e->P, io, grid, e->stream, ev0, ev1, waves))
         return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
+    e->last_rollout_waves = waves;
     if (e->timing) {
         e->ev_valid = true;
         e->ev_slow = false;
@@ -789,6 +836,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(hipMemset(e->d_slow_list, 0xff, sizeof(int) * N));
     A(copy_h2d(e->d_tables, &T, sizeof(T), e->stream));
     for (auto& ev : e->ev) A(hipEventCreate(&ev));
+    for (auto& ev : e->roll.ev) A(hipEventCreate(&ev));
     if (err != hipSuccess) {
         free_all(e);
         delete e;
@@ -1119,6 +1167,12 @@ int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int
             ? nullptr : (const void*)((const char*)actions_dev + (size_t)(i % ring_len) * stride);
         if (int rc = launch_step(e, a, action_kind, bins, out)) return rc;
     }
+    return EVC_OK;
+}
+
+int evc_last_rollout_waves(evc_engine* e, int32_t* waves) {
+    if (!e || !waves) return fail(EVC_EINVAL, "null argument");
+    *waves = e->last_rollout_waves;
     return EVC_OK;
 }
 

@@ -88,8 +88,14 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
 #endif
 
 // KIND: 0 = greedy, 1 = random (Philox), 2 = replay of a pre-staged action ring (evc_rollout with EVC_ACTION_F32 / _DISCRETE)
-template <bool PROJECT, int WORDS, int KIND>
-__global__ __launch_bounds__(256, EVC_ROLLOUT_WAVES) void rollout_kernel(Params P, RolloutIO io) {
+// WAVES: wavefronts per SIMD the register allocation is held to.  3 (168 VGPRs) leaves the projecting copies ~570 spilled
+// VGPRs, all of them around the rare projection branch: free on quiet days (4.1 / 5.0e9 env-steps/s greedy / random against
+// 3.2 / 4.0e9 at 2), but on the reference's GMM days at Caltech three quads in four take that branch at midday and the scratch
+// traffic is what the wavefronts wait for (SQ_WAIT_ANY 327 of 650 wave cycles): 2 (256 VGPRs, ~90 spilled) runs those 2.40
+// against 1.95e9.  JPL's GMM days prefer 3 again (2.36 against 2.16e9).  The engine therefore MEASURES (evc_engine.hip,
+// launch_rollout): the projecting kernels exist at both settings and the faster one on the caller's own workload is kept.
+template <bool PROJECT, int WORDS, int KIND, int WAVES = EVC_ROLLOUT_WAVES>
+__global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO io) {
     __shared__ RolloutLds S;
     LdsNet& net = S.net;
     auto& st_mulw = S.st_mulw;

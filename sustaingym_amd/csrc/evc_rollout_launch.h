@@ -20,7 +20,9 @@ struct RolloutIO {
 };
 
 // Launches rollout_kernel<P.project, (P.G + 1) / 2, policy kind (0 greedy, 1 random, 2 replay)> on `stream`; with start / stop events
-// the launch carries them (hipExtLaunchKernel: the dispatch's own begin / end timestamps).  false: unsupported class count.
-bool launch_rollout_kernel(const Params& P, const RolloutIO& io, int grid, hipStream_t stream, hipEvent_t start, hipEvent_t stop);
+// the launch carries them (hipExtLaunchKernel: the dispatch's own begin / end timestamps).  waves = 2 | 3: the register
+// budget of the projecting kernels (wavefronts per SIMD; rollout_kernel's WAVES).  false: unsupported class count.
+bool launch_rollout_kernel(const Params& P, const RolloutIO& io, int grid, hipStream_t stream, hipEvent_t start, hipEvent_t stop,
+                           int waves = 3);
 
 }  // namespace evc

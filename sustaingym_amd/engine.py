@@ -298,6 +298,13 @@ class StepEngine:
             check(self.lib.evc_join(self.handle), 'evc_join')
         return out
 
+    def last_rollout_waves(self) -> int:
+        """Register budget (wavefronts per SIMD) of the last fused rollout launch: the engine times its launches and keeps the
+        faster of the two builds of the projecting kernels (``evc_last_rollout_waves``)."""
+        w = C.c_int32()
+        check(self.lib.evc_last_rollout_waves(self.handle, C.byref(w)), 'evc_last_rollout_waves')
+        return w.value
+
     def set_policy_seed(self, seed: int, env_id_base: int = 0) -> None:
         """Seed of the device-resident random policy; ``env_id_base`` = global id of environment 0."""
         check(self.lib.evc_set_policy_seed(self.handle, C.c_uint64(int(seed) & (2 ** 64 - 1)), int(env_id_base)),

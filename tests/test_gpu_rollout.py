@@ -227,3 +227,32 @@ def test_discrete_ring_16384_gmm_days_against_the_oracle(site, fused):
     assert not (eng.env_scalars()['status'] & 2).any()
     eng.close()
 
+
+
+def test_both_register_budgets_of_the_rollout_kernel_give_the_same_day():
+    """The projecting rollout kernels are built at two register budgets (2 / 3 wavefronts per SIMD) and the engine keeps the
+    one that is faster on the caller's workload (launch_rollout, evc_last_rollout_waves): same arithmetic, so the same day
+    played from the same state must come out bit for bit the same whichever build ran — and the engine must try both."""
+    import torch
+    if os.environ.get('EVC_ROLLOUT_WAVES'):
+        pytest.skip('EVC_ROLLOUT_WAVES fixes the setting')
+    net, eng = _gmm_engine('caltech', 'Summer 2019', 4096, 512, seed=31)
+    eng.set_policy_seed(5)
+    eng.reset()
+    torch.cuda.synchronize()
+    snap = eng.get_state()
+    seen, first = set(), None
+    for rep in range(9):
+        eng.set_state(snap)
+        out = eng.rollout(policy='random', steps=288)
+        torch.cuda.synchronize()                        # a finished launch is what the engine's timing reads at the next one
+        seen.add(eng.last_rollout_waves())
+        got = {k: to_host(v).copy() for k, v in out.items()}
+        got.update(eng.get_state())
+        if first is None:
+            first = got
+        else:
+            for k in first:
+                assert np.array_equal(first[k], got[k], equal_nan=True), (rep, k, eng.last_rollout_waves())
+    assert seen == {2, 3}, seen
+    eng.close()
