@@ -220,11 +220,11 @@ class EvWorkload:
         self.run(8)
         if eng.pipelined_steps() - before == 8:
             # Pipelined halves: a step is two launches that overlap the neighbouring steps' — what the GPU needs per step is
-            # the PERIOD of the launch train, measured with HIP events on the stream that joins it (windows of M steps;
+            # the PERIOD of the launch train, measured with HIP events on the stream that joins it (windows of M = 288 steps;
             # the first record makes the stream busy, so the window's first step is ordered behind it like a caller's
             # actions would be), and a half launch's own begin-to-end time under that overlap (what a kernel trace shows).
             torch = self.torch
-            M = 96
+            M = 288
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             periods, halves = [], []
             for _ in range(max(3, launches // M)):
@@ -336,7 +336,7 @@ def roofline_record(w: EvWorkload, timed: dict, bytes_per_env_step: int) -> dict
             'launches_per_step': 2, 'algorithmic_bytes_per_launch': alg // 2, 'algorithmic_bytes_per_step': alg,
             'basis': 'achieved = algorithmic bytes per STEP / step period.  A step is two half-batch launches on two streams '
                      '(evc_set_pipeline) that overlap the neighbouring steps\' launches; step_period_ms = HIP events on the joining '
-                     'stream over windows of 96 steps; half_launch_ms = one launch\'s own begin-to-end time under that overlap '
+                     'stream over windows of 288 steps; half_launch_ms = one launch\'s own begin-to-end time under that overlap '
                      '(hipExtLaunchKernel events; what a kernel trace reports per dispatch); step_alone_ms = first begin to last end '
                      'of a step issued alone',
             'step_period_ms': round(avg, 5), 'avg_kernel_ms': round(float(h.mean()), 5),

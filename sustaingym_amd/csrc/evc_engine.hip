@@ -58,7 +58,7 @@ constexpr int kQlenRing = 288;           // one report per period of a day
 #define EVC_PROJ_WAVES 3                // wavefronts per SIMD the PROJECTING lean compact kernels are held to (evc_cquad.h, WAVES)
 #endif
 constexpr int kDrainLookBack = 12, kDrainLookAhead = 36;   // periods of the day around the current one whose reports decide the step's mode
-constexpr int kPipeSkewUs = 0;             // start skew (us) of the second half of a pipelined step train (launch_split): measured, no gain
+constexpr int kPipeSkewUs = 0;             // start skew (us) of the second half of a pipelined step train (launch_split): measured twice, no reliable gain
 constexpr int kDrainMaxQueueDefault = 16;   // in-kernel drain only while NO step of the last day queued more than this (EVC_DRAIN_MAXQ overrides)
 
 struct evc_engine {
@@ -124,6 +124,7 @@ struct evc_engine {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
     bool halves_pending = false, side_warmed = false, last_split = false;
+    unsigned train_len = 0, prev_train_len = 0;   // pipelined steps since the last join, and in the train before it
     unsigned long long split_steps = 0;   // steps that ran as two half launches (evc_pipelined_steps) ...
     unsigned long long fork_steps = 0;    // ... and how many of them had to be ordered behind pending work of the engine's stream
     // fused rollout: which register budget of the projecting kernels is faster on the caller's workload (launch_rollout)
@@ -487,12 +488,16 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         const bool fork = fork_mode >= 0 ? fork_mode != 0 : hipStreamQuery(e->stream) != hipSuccess;
         if (fork) (void)hipEventRecord(e->fork_ev, e->stream);
         // Cold start (nothing pending: the first pipelined step, or the first after a join): two launches that begin together
-        // share the GPU evenly and end together, tails side by side; the trains drift apart over the next steps.  Starting
-        // the second half's train late by half a launch (EVC_PIPE_SKEW_US) was measured: the driver's 20-step window gains
-        // 1 us per step in the median and loses the skew itself, and the steady-state period is WORSE (24.4 against 23.4 us:
-        // the phase the trains settle into by themselves is better than the one imposed).  Off by default.
+        // share the GPU evenly and end together, tails side by side — 32 us per step, worse than one launch — and the trains
+        // need five to ten steps to drift apart.  EVC_PIPE_SKEW_US > 0 starts the second half's train that much later (a
+        // one-wavefront sleep kernel) for a caller that has been free-running (its previous train had at least four steps; one
+        // that joins after every step never sees it).  Measured twice on windows of 20 steps, medians of 8 interleaved runs:
+        // 27.9 -> 26.7 us per step with the skew on every cold start, 27.8 -> 28.3 with this rule; long runs unchanged.  No
+        // reliable gain: off by default.
         static const int skew_us = getenv("EVC_PIPE_SKEW_US") ? atoi(getenv("EVC_PIPE_SKEW_US")) : kPipeSkewUs;
         const bool cold = !e->halves_pending;
+        if (cold) { e->prev_train_len = e->train_len; e->train_len = 0; }
+        e->train_len++;
         for (int h = 0; h < 2; h++) {
             StepIO ioh = io;
             ioh.quad_lo = h ? mid : 0;
@@ -507,7 +512,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             if (grid > split_cap) grid = split_cap;
             if (grid >= 8) grid -= grid % 8;
             if (fork) (void)hipStreamWaitEvent(e->side[h], e->fork_ev, 0);
-            if (cold && h == 1 && skew_us > 0 && !e->timing)
+            if (cold && h == 1 && skew_us > 0 && !e->timing && e->prev_train_len >= 4)
                 hipLaunchKernelGGL(skew_kernel, dim3(1), dim3(64), 0, e->side[h], (unsigned)skew_us * 100u);
             if (e->timing)
                 hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, e->side[h], e->ev[h ? 4 : 0], e->ev[h ? 5 : 1], 0, Ph, ioh);
