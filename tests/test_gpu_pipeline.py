@@ -126,3 +126,28 @@ def test_pipelined_halves_against_the_oracle(monkeypatch):
     assert np.array_equal(dep, odep) and np.array_equal(est, oest)
     np.testing.assert_allclose(rem, orem, rtol=1e-12, atol=1e-12)
     eng.close()
+
+
+def test_rollout_as_a_loop_of_steps_is_pipelined_too(monkeypatch):
+    """evc_rollout replaying a pre-staged ring as a loop of evc_step launches (EVC_ROLLOUT_FUSED=0) goes through the same
+    launch path: with the pipelined mode on its periods are half launches, and StepEngine.rollout joins before it returns."""
+    import torch
+    from sustaingym_amd.network import caltech_acn
+    monkeypatch.setenv('EVC_DRAIN', '1')
+    monkeypatch.setenv('EVC_ROLLOUT_FUSED', '0')
+    net = caltech_acn()
+    wl = make_workload(net, N, bank_slots=512, seed=12, moer_days=3)
+    one, two = _engine(net, wl, True, 1), _engine(net, wl, True, 2)
+    assert np.array_equal(to_host(one.reset()), to_host(two.reset()))
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(8)
+    ring = torch.rand((4, N, net.num_stations), dtype=torch.float32, device='cuda', generator=gen)
+    o1 = one.rollout(actions=ring, steps=60, accumulate_returns=False)      # (returns are a debug-kernel output: never split)
+    o2 = two.rollout(actions=ring, steps=60, accumulate_returns=False)
+    torch.cuda.synchronize()
+    assert two.pipelined_steps() == 60
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    _assert_same(_state(one), _state(two), 'after the looped rollout')
+    one.close()
+    two.close()
