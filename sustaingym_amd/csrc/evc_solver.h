@@ -772,9 +772,11 @@ __device__ EVC_SOLVE_ENV_INLINE void solve_env(const Params& P, const StepIO& io
 // (13 KB + 4 x 5 KB): EVC_SOLVER_WAVES workgroups per CU are resident, i.e. that many solves per SIMD in flight.  A solve
 // is a chain of dependent float64 ladders, LDS round trips, square roots and divides on one wavefront — all latency —
 // so the slow path's throughput is the number of wavefronts in flight (round 1/2: one 64-thread workgroup per solve,
-// 25 KB of LDS and 250 VGPRs each, 6 per CU).
+// 25 KB of LDS and 250 VGPRs each, 6 per CU).  Round 3, with each half's slow launch running under the other half's
+// streaming launch (pipelined halves): 2 per SIMD (256 VGPRs, 4 spilled instead of 83) beats 3 on JPL's GMM days — 47.8 - 48.4
+// against 48.8 - 49.6 us per step pipelined, 52.3 - 53.2 against 55.1 - 56.2 as one launch; 4 (128 VGPRs, 173 spilled): 54.0.
 #ifndef EVC_SOLVER_WAVES
-#define EVC_SOLVER_WAVES 3
+#define EVC_SOLVER_WAVES 2
 #endif
 template <int WORDS>
 __global__ __launch_bounds__(256, EVC_SOLVER_WAVES) void solver_step_kernel(Params P, StepIO io) {

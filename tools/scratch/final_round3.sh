@@ -1,6 +1,6 @@
 #!/bin/bash
-# what produced profiles/r3g_*: the GPU suite, tools/profile.sh, the driver's command
-TAG=${1:-r3g}
+# what produced profiles/r3h_*: the GPU suite, tools/profile.sh, the driver's command
+TAG=${1:-r3h}
 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
 bash tools/profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver.json 2>/dev/null
