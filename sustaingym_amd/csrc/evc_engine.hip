@@ -59,6 +59,7 @@ constexpr int kQlenRing = 288;           // one report per period of a day
 #endif
 constexpr int kDrainLookBack = 12, kDrainLookAhead = 36;   // periods of the day around the current one whose reports decide the step's mode
 constexpr int kPipeSkewUs = 0;             // start skew (us) of the second half of a pipelined step train (launch_split): measured twice, no reliable gain
+constexpr int kDrainMaxQueuePipelined = 256; // ... pipelined halves: a workgroup's drain runs under the other half's launches (JPL GMM days 48.4 -> 46.9 us per step)
 constexpr int kDrainMaxQueueDefault = 16;   // in-kernel drain only while NO step of the last day queued more than this (EVC_DRAIN_MAXQ overrides)
 
 struct evc_engine {
@@ -95,6 +96,7 @@ struct evc_engine {
     bool warmed = false;          // both lean streaming copies have been launched once
     int drain_override = -1;      // EVC_DRAIN=0/1 forces a mode (measurements)
     int drain_max_queue = kDrainMaxQueueDefault;
+    int drain_max_queue_pipelined = kDrainMaxQueuePipelined;
     int* d_idbuf = nullptr;       // reset ids/slots staging [2N]
     double* d_metrics = nullptr;  // [8]
     double* d_maxprofit = nullptr;  // [bank_slots] env.py:422-429 of the episode in each slot
@@ -441,7 +443,8 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
             return (a == INT_MAX || b == INT_MAX) ? INT_MAX : a + b;
         };
         for (int i = 0; i < kQlenRing; i++) { const int v = reported(i); if (v > recent) recent = v; }
-        drain = recent <= e->drain_max_queue;
+        const int max_queue = e->pipeline == 2 ? e->drain_max_queue_pipelined : e->drain_max_queue;
+        drain = recent <= max_queue;
         if (!drain && recent != INT_MAX) {
             // A day with a congested part.  The ring is indexed by the period of the day, so the slots around this step's hold
             // the last reports for this time of day — today's behind it (as far as the GPU has come), yesterday's ahead.
@@ -453,7 +456,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 const int v = reported((here + d + kQlenRing) % kQlenRing);
                 if (v > around) around = v;
             }
-            drain = around <= e->drain_max_queue;
+            drain = around <= max_queue;
         }
         if (e->drain_override >= 0) drain = e->drain_override != 0;
         // capacity guard, AFTER the override: a workgroup's list must hold every environment it steps (a queued row that found
@@ -890,7 +893,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     }
     if (const char* s = getenv("EVC_DRAIN"))
         if (*s && strcmp(s, "auto") != 0) e->drain_override = atoi(s) != 0 ? 1 : 0;
-    if (const char* s = getenv("EVC_DRAIN_MAXQ")) e->drain_max_queue = atoi(s);
+    if (const char* s = getenv("EVC_DRAIN_MAXQ")) e->drain_max_queue = e->drain_max_queue_pipelined = atoi(s);
     *out = e;
     return EVC_OK;
 }
