@@ -49,6 +49,18 @@ __device__ __forceinline__ double row_allreduce_f64(double v) {
     v += dpp_f64<0x140, 0xf, true>(v);   // row_mirror
     return v;
 }
+// the same butterfly in float32 (each step is one v_add_f32 with a DPP operand)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_allreduce_f32(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    return v;
+}
 // does any lane of MY row have `flag` set?
 __device__ __forceinline__ bool row_any(bool flag, unsigned row) {
     const unsigned long long b = __ballot(flag);
@@ -144,6 +156,47 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
     }
     double nu = 0.0, lo = 0.0, hi = 64.0;
     bool run = on;
+#ifdef EVC_FILL_WARM32
+    // float32 passes first (same safeguarded Newton; full-rate arithmetic, one-instruction DPP adds, v_rcp_f32 instead of
+    // the IEEE float64 divide) find the multiplier to ~1e-6; the float64 loop below then starts beside the solution — one
+    // Newton step on the right active set lands, the next pass confirms — instead of walking there from nu = 0.  Only
+    // the START of the float64 iteration changes: bracket, safeguards and stopping rule are untouched, so whatever the
+    // float32 passes return the result meets the cap to 1e-13 as before.
+    {
+        float bf[kSlots], hf[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            bf[j] = act[j] * (float)Consts::ACTION_SCALE_FACTOR;
+            hf[j] = (float)h[j];
+        }
+        const float capf = (float)cap;
+        float nuf = 0.0f, lof = 0.0f, hif = 64.0f;
+        bool runf = on;
+        for (int it = 0; it < 10 && __ballot(runf) != 0ull; it++) {
+            float part = 0.0f;
+            unsigned nfree = 0u;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) {
+                const float v = bf[j] - nuf;
+                part += in_g[j] ? fminf(fmaxf(v, 0.0f), hf[j]) : 0.0f;
+                nfree += (in_g[j] && v > 0.0f && v <= hf[j] && hf[j] > 0.0f) ? 1u : 0u;
+            }
+            const float f = row_allreduce_f32(part) - capf;
+            const unsigned kfree = row_allreduce_u32(nfree);
+            if (runf) {
+                if (fabsf(f) <= 1e-5f * capf || kfree == 0u) {
+                    runf = false;                 // close enough, or a flat piece (the float64 loop owns the breakpoints)
+                } else {
+                    if (f > 0.0f) lof = nuf; else hif = nuf;
+                    float nxt = nuf + f * __builtin_amdgcn_rcpf((float)kfree);
+                    if (!(nxt > lof && nxt < hif)) nxt = 0.5f * (lof + hif);
+                    nuf = nxt;
+                }
+            }
+        }
+        if (on) nu = (double)nuf;
+    }
+#endif
     for (int it = 0; it < 80 && __ballot(run) != 0ull; it++) {
         if (pass_count) *pass_count += 1ull;
         double part = 0.0;
