@@ -197,7 +197,11 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
         if (on) nu = (double)nuf;
     }
 #endif
+#ifdef EVC_ABL_FILL_PASSES         /* ablation builds only (wrong results): the Newton loop cut off after so many passes */
+    for (int it = 0; it < (EVC_ABL_FILL_PASSES) && __ballot(run) != 0ull; it++) {
+#else
     for (int it = 0; it < 80 && __ballot(run) != 0ull; it++) {
+#endif
         if (pass_count) *pass_count += 1ull;
         double part = 0.0;
         unsigned nfree = 0u;
