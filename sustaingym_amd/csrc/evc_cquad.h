@@ -58,19 +58,6 @@ struct CquadLds {
     int local_list[kDrainListMax];   // ... (the engine enables DRAIN only while a workgroup steps at most that many environments)
 };
 
-// Early drain (EVC_EARLY_DRAIN): what the workgroup's drainer wavefront needs while its siblings are still streaming — a
-// solver workspace of its own (the images of the union above are in use) and the hand-off words.  Exists only in the
-// DRAIN kernels' LDS (the others keep their 4 workgroups per CU).
-struct DrainState {
-    SolverWs ws;
-    int drainer;                // 0: nobody yet; w + 1: wavefront w left the streaming loop to solve the list as it fills
-    int done_waves;             // siblings that have finished their streaming work (all their list entries are in)
-    int drain_next;             // list entries [0, drain_next) are solved
-    int pad_;
-};
-template <bool DRAIN> struct CquadShared { CquadLds S; };
-template <> struct CquadShared<true> { CquadLds S; DrainState D; };
-
 // The in-kernel drain behind a real call (DRAIN kernels): inlined, the slow path's code and live ranges cost
 // the streaming path 5 us per step; with explicit arguments the caller keeps them alive (and spilled) through
 // the whole streaming loop, 3 us (both measured).  So the callee takes ONE constant — the LDS address of the
@@ -86,44 +73,12 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
     const Params& P = *(const Params*)ka;
     const StepIO& io = *(const StepIO*)(ka + kStepIOKernargOffset);
     typedef __attribute__((address_space(3))) CquadLds LdsImage;
-    const int lane = (int)__lane_id();            // wave 0 of the workgroup: lane = thread id, without asking the caller for it
-#ifdef EVC_EARLY_DRAIN
-    // bit 0 of the argument: called by the drainer wavefront while its siblings stream — solve the entries as they
-    // arrive and return once the three siblings are done and the list is empty; otherwise (after the workgroup's
-    // barrier) whatever is left
-    const bool early = (rfl((int)lds) & 1) != 0;
-    typedef __attribute__((address_space(3))) CquadShared<true> LdsBoth;
-    CquadShared<true>& B = *(CquadShared<true>*)(LdsBoth*)(size_t)(unsigned)(rfl((int)lds) & ~1);
-    CquadLds& S = B.S;
-    DrainState& D = B.D;
-    SolverLds L(S.net, D.ws);
-    auto listed = [&]() {
-        const int c = __hip_atomic_load(&S.local_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return rfl(c < kDrainListMax ? c : kDrainListMax);
-    };
-    int next = rfl(__hip_atomic_load(&D.drain_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    for (;;) {
-        if (next < listed()) {
-            solve_env<WORDS>(P, io, L, lane, rfl(__hip_atomic_load(&S.local_list[next], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
-            next++;
-            continue;
-        }
-        if (!early) break;
-        // a sibling adds itself to done_waves AFTER its last list entry (LDS operations of a wavefront execute in order)
-        if (rfl(__hip_atomic_load(&D.done_waves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 3) {
-            if (next >= listed()) break;
-            continue;
-        }
-        __builtin_amdgcn_s_sleep(16);
-    }
-    if (lane == 0) __hip_atomic_store(&D.drain_next, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
     CquadLds& S = *(CquadLds*)(LdsImage*)(size_t)(unsigned)rfl((int)lds);
+    const int lane = (int)__lane_id();            // wave 0 of the workgroup: lane = thread id, without asking the caller for it
     const int count = rfl(S.local_count < kDrainListMax ? S.local_count : kDrainListMax);
     // the slow path works on the workgroup's tables and on the memory of the per-step images (CquadLds::Images)
     SolverLds L(S.net, S.u.solver_workspace);
     for (int i = 0; i < count; i++) solve_env<WORDS>(P, io, L, lane, rfl(S.local_list[i]));
-#endif
 }
 
 // DRAIN: no slow kernel is launched after this one.  Each workgroup keeps the environments whose projection
@@ -144,12 +99,7 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
 template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES>
 __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params P, StepIO io) {
     static_assert(!DRAIN || (PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");
-#ifdef EVC_EARLY_DRAIN
-    __shared__ CquadShared<DRAIN> B;
-    CquadLds& S = B.S;
-#else
     __shared__ CquadLds S;
-#endif
     __shared__ double dbg_img[DBG ? 4 : 1][4][64];     // unused (and dropped) in the lean kernels
     LdsNet& net = S.net;
     auto& st_mulw = S.st_mulw;
@@ -196,22 +146,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     auto wg_quad = [&](int k) { const int qd = wg_first + (k & 3) + (k >> 2) * walk.stride; return qd < walk.hi ? qd : -1; };
     auto take_quad = [&]() {
         int k = 0;
-#ifdef EVC_EARLY_DRAIN
-        // Early drain: the first wavefront that comes for another quad while the workgroup's list holds an environment
-        // takes none — it finishes the quad it has, leaves the loop and solves the list as it fills (below), while its
-        // siblings share out the remaining quads through the same counter.  A solve is ~30 us of latency on one
-        // wavefront: started where it is found it runs beside the workgroup's streaming work instead of after it.
-        if constexpr (DRAIN) {
-            if (lane == 0u) {
-                bool leave = false;
-                if (__builtin_expect(S.local_count != 0, 0))
-                    leave = B.D.drainer == 0 && atomicCAS(&B.D.drainer, 0, (int)wv + 1) == 0;
-                k = leave ? -1 : __hip_atomic_fetch_add(&S.next_quad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            k = rfl(k);
-            return k < 0 ? -1 : wg_quad(k);
-        }
-#endif
         if (lane == 0u) k = __hip_atomic_fetch_add(&S.next_quad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return wg_quad(rfl(k));
     };
@@ -248,9 +182,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     if (tid == 0u) S.next_quad = 4;
     if (DRAIN && tid == 0u) {
         S.local_count = 0;
-#ifdef EVC_EARLY_DRAIN
-        if constexpr (DRAIN) { B.D.drainer = 0; B.D.done_waves = 0; B.D.drain_next = 0; }
-#endif
         // the other control block still holds the PREVIOUS step's total (its launch is complete): report it to
         // the host (drain mode decision) and clear it for the next step
         if (blockIdx.x == 0u) queue_begin_drain(P, P.slow_count_next[0]);               // (a half launch of the pipelined mode has control blocks of its own)
@@ -445,7 +376,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                         if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr);
 #endif
                     }
-#ifdef EVC_ABL_NO_REVERIFY          /* ablation builds only (wrong beside violated multi-class rows): no second evaluation of the rows */
+#ifdef EVC_ABL_NO_REVERIFY          /* ablation builds only (WRONG results): no second evaluation of the rows, a filled environment is never queued */
                     anyviol = anyviol && !fill;
 #else
                     unsigned cv2;
@@ -783,20 +714,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         quad = quad_next;
     }
 
-#ifdef EVC_EARLY_DRAIN
-    if constexpr (DRAIN) {
-        const unsigned lds_b = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&B;
-        if (__builtin_expect(rfl(B.D.drainer) == (int)wv + 1, 0)) {
-            drain_local_list<WORDS>(lds_b | 1u);
-        } else if (lane == 0u) {
-            __hip_atomic_fetch_add(&B.D.done_waves, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        __syncthreads();
-        // entries nobody left the loop for (queued in the last iterations of every wavefront)
-        const int count = S.local_count < kDrainListMax ? S.local_count : kDrainListMax;
-        if (__builtin_expect(count > B.D.drain_next, 0) && wv == 0u) drain_local_list<WORDS>(lds_b);
-    }
-#else
     if (DRAIN) {
         __syncthreads();                       // every wave's queue entries are in the list; the images are free
         const int count = S.local_count < kDrainListMax ? S.local_count : kDrainListMax;
@@ -806,7 +723,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 #endif
         }
     }
-#endif
 }
 
 }  // namespace evc
