@@ -72,3 +72,27 @@ def test_product_does_not_import_oracle():
             if f.endswith(('.py', '.h', '.hip', '.cpp')):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in src.lower() or f in (), (f, 'product code must not reference the oracle')
+
+
+def test_product_build_defines_no_measurement_switch():
+    """The kernels carry ablation / measurement switches (EVC_ABL_*: wrong results, timing only; EVC_FILL_WARM32,
+    EVC_PREFETCH_EARLY, ...: rejected variants kept for A/B builds via tools/build_variant.sh).  The product Makefile
+    and build() must define none of them, and every switch the sources test must be documented in DESIGN.md or
+    tools/README.md so that a variant library is never mistaken for the product."""
+    import os
+    import re
+    root = os.path.dirname(_lib.__file__)
+    repo = os.path.dirname(root)
+    mk = open(os.path.join(root, 'csrc', 'Makefile')).read()
+    entry = open(os.path.join(repo, '__graft_entry__.py')).read()
+    assert '-DEVC_' not in mk and '-DEVC_' not in entry
+    switches = set()
+    for f in os.listdir(os.path.join(root, 'csrc')):
+        if f.endswith(('.h', '.hip')):
+            src = open(os.path.join(root, 'csrc', f)).read()
+            switches |= set(re.findall(r'#\s*if(?:def|ndef)?\s+(?:defined\()?(EVC_ABL_\w+)', src))
+    docs = open(os.path.join(repo, 'DESIGN.md')).read() + open(os.path.join(repo, 'tools', 'README.md')).read() \
+        + open(os.path.join(repo, 'tools', 'scratch', 'abl_fill.sh')).read()
+    assert switches, 'no ablation switch found: the pattern of this test is stale'
+    missing = sorted(s for s in switches if s not in docs)
+    assert not missing, f'ablation switches without a word in DESIGN.md / tools/README.md: {missing}'
