@@ -116,9 +116,13 @@ __device__ __forceinline__ EnvLoads issue_loads(const Params& P, const StepIO& i
         // station lane pulls the entry's words with a lane gather (ds_bpermute)
         __shared__ int entry_of[4][kWave];
         int* cell = entry_of[wave_in_block >= 0 ? wave_in_block : (int)(threadIdx.x >> 6)];
+        // The entry rows are requested beside the scalars (bound: the whole row; entries beyond the count A are masked by
+        // `lane < A` below) instead of behind them through a descriptor of A entries: one dependent round trip fewer per
+        // queued environment — the slow path is memory latency, profiles/r3_solver_stats.txt (JPL GMM day 47.1 -> 46.8 us
+        // per step pipelined, Caltech 33.3 -> 33.0; profiles/r3_fill_ab.txt).
+        const double rem_e = buf_ld_f64(row_rsrc(P.rem + (size_t)env * n, n * 8u), ul * 8u);
+        const unsigned w_e = buf_ld_u32(row_rsrc(P.depest + (size_t)env * n, n * 4u), ul * 4u);
         const unsigned A = (unsigned)(rfl(L.s1.z) >> kCountShift) & 0x7fu;
-        const double rem_e = buf_ld_f64(row_rsrc(P.rem + (size_t)env * n, A * 8u), ul * 8u);
-        const unsigned w_e = buf_ld_u32(row_rsrc(P.depest + (size_t)env * n, A * 4u), ul * 4u);
         // (LDS executes a wave's ds instructions in issue order: compiler barriers suffice)
         cell[lane] = 0;
         asm volatile("" ::: "memory");
