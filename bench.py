@@ -424,7 +424,7 @@ def secondary_days(site, episodes, dev_index, battery) -> dict:
     return rec
 
 
-def secondary_rollout(policy, dev_index, battery, episodes='synthetic') -> dict:
+def secondary_rollout(policy, dev_index, battery, episodes='synthetic', site='caltech') -> dict:
     """Whole episodes under a device-resident policy (BaseAlgorithm.run over GreedyAlgorithm / RandomAlgorithm,
     algorithms/base.py:63-88, baselines.py:22-51): 65 536 environments x 288 periods in ONE launch of the fused rollout
     kernel (csrc/evc_rollout.h: state in registers, no per-period action read / observation write), beside the same
@@ -433,7 +433,7 @@ def secondary_rollout(policy, dev_index, battery, episodes='synthetic') -> dict:
     from oracle import binding as ob
     from sustaingym_amd.hostio import to_host
     N = 65536
-    w = EvWorkload('caltech', N, dev_index, 0, project=True, episodes=episodes, phase='sync', battery=battery)
+    w = EvWorkload(site, N, dev_index, 0, project=True, episodes=episodes, phase='sync', battery=battery)
     eng = w.eng
     eng.set_policy_seed(7)
     dev = w.dev
@@ -474,7 +474,7 @@ def secondary_rollout(policy, dev_index, battery, episodes='synthetic') -> dict:
     # (profiles/r3_rollout_*.json); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md).
     valu = None
     try:
-        valu = json.load(open(os.path.join(ROOT, 'profiles', f'r3_rollout_caltech_{"synthetic" if episodes == "synthetic" else "gmm"}_{policy}.json')))['SQ_INSTS_VALU']
+        valu = json.load(open(os.path.join(ROOT, 'profiles', f'r3_rollout_{site}_{"synthetic" if episodes == "synthetic" else "gmm"}_{policy}.json')))['SQ_INSTS_VALU']
     except Exception:
         pass
     peak = 256 * 4 * 2.4e9 / 2
@@ -482,7 +482,7 @@ def secondary_rollout(policy, dev_index, battery, episodes='synthetic') -> dict:
                                       'achieved': round(N * EPISODE / (kernel_ms * 1e-3) * valu / 1e9, 1), 'peak': round(peak / 1e9, 1),
                                       'unit': 'G wave-instructions/s', 'frac': round(N * EPISODE / (kernel_ms * 1e-3) * valu / peak, 4),
                                       'note': 'float64 instructions issue at half this rate; SQ_ACTIVE_INST_VALU says the vector ALUs are busy ~68 % of the launch (DESIGN.md 4.6)'}
-    return {'workload': f'{N} x {w.n}-station (caltech), {"synthetic days" if episodes == "synthetic" else "device-generated GMM days"}, '
+    return {'workload': f'{N} x {w.n}-station ({site}), {"synthetic days" if episodes == "synthetic" else "device-generated GMM days"}, '
                         f'projection on, {policy} policy on the device, whole episodes (288 periods), autoreset',
             'env_steps_per_s': round(N * EPISODE / fused, 1), 'episode_ms': round(fused * 1e3, 4),
             'us_per_period': round(fused / EPISODE * 1e6, 3), 'launches_per_episode': 1,
@@ -534,6 +534,110 @@ def secondary_vector_env_api(dev_index, battery) -> dict:
     out['sb3_numpy_path'] = {'workload': f'{Nn} x 54-station (caltech) EVChargingVectorEnv.step, numpy in / numpy out (page-locked, zero_copy): '
                                          f'{a.nbytes / 1e6:.1f} MB of actions in and {Nn * 146 * 4 / 1e6:.1f} MB of observations out per step over PCIe',
                              'ms_per_step': round(dt * 1e3, 5), 'env_steps_per_s': round(Nn / dt, 1), 'pcie_inclusive': True}
+    return out
+
+
+def secondary_closed_loop(dev_index, battery) -> dict:
+    """Closed loop (train_stable_baselines.py:271-275): a device policy that READS the observation of step k
+    to produce the action of step k + 1 — the caller's own greedy, ``sign(demands)`` as a torch op — on the headline workload
+    (65 536 Caltech environments, synthetic days, projection on, staggered phases).  Forms: (a) one launch per step, the
+    policy on the engine's stream; (b) pipelined halves with a join after every step (what a caller that treats the step as
+    synchronous gets); (c) pipelined halves with each half's policy on that half's stream (evc_pipeline_half): the policy of
+    one half runs under the other half's step, no join; (d) EVChargingVectorEnv.step(output='torch') on device-generated GMM
+    days, synchronous and with pipeline=2 + per-half policies.  Beside them the open-loop figure of the same engine."""
+    import torch
+    N = 65536
+    dev = torch.device('cuda', dev_index)
+    out = {}
+    w = EvWorkload('caltech', N, dev_index, 0, project=True, battery=battery, pipeline=1)
+    n = w.n
+    eng = w.eng
+    acts = torch.zeros((N, n), dtype=torch.float32, device=dev)
+    obs = w.out['obs']
+    demands = obs[:, :n]
+    ptr = acts.data_ptr()
+    K = 576
+
+    def timed(body, join=False, steps=K):
+        for _ in range(48):
+            body()
+        eng.join()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            body()
+        host = (time.perf_counter() - t0) / steps
+        eng.join()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        return {'ms_per_step': round(dt * 1e3, 5), 'env_steps_per_s': round(N / dt, 1), 'host_issue_us_per_step': round(host * 1e6, 2)}
+
+    def single():
+        torch.sign(demands, out=acts)                 # greedy by the caller: reads this step's observation
+        w.step(ptr)
+    out['single_launch'] = dict(timed(single), form='one launch per step; policy = torch.sign(obs[:, :n], out=actions) on the engine stream')
+    out['open_loop_single_launch'] = timed(lambda: w.step(ptr))
+    eng.set_pipeline(2)
+
+    def joined():
+        torch.sign(demands, out=acts)
+        w.step(ptr)
+        eng.join()
+    out['pipelined_joined'] = dict(timed(joined), form='two half launches per step, evc_join after every step, policy on the engine stream')
+    halves = eng.pipeline_halves()
+    views = [(demands[sl], acts[sl], st) for sl, st in halves]
+
+    def per_half():
+        for d, a, st in views:
+            with torch.cuda.stream(st):
+                torch.sign(d, out=a)
+        w.step(ptr)
+    before = eng.pipelined_steps(ordered=True)
+    out['pipelined_per_half_policy'] = dict(timed(per_half), form='two half launches per step, each half\'s policy enqueued on that '
+                                            'half\'s stream (evc_pipeline_half): no join, no fork event')
+    after = eng.pipelined_steps(ordered=True)
+    out['pipelined_per_half_policy']['pipelined_steps'] = int(after[0] - before[0])
+    out['pipelined_per_half_policy']['steps_ordered_behind_the_engine_stream'] = int(after[1] - before[1])
+    out['open_loop_pipelined'] = timed(lambda: w.step(ptr))
+    w.close()
+
+    # the API north_star names, on the reference's own episode distribution
+    from sustaingym_amd.envs import EVChargingVectorEnv
+    from sustaingym_amd.event_generation import DeviceGMMTraceGenerator
+    for pipeline in (1, 2):
+        venv = EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2019', seed=0), num_envs=N, output='torch',
+                                   device=dev_index, charge_calculation=battery, pipeline=pipeline)
+        o, _ = venv.reset(seed=0)
+        d = o['demands']
+        a = torch.zeros((N, venv.num_stations), dtype=torch.float32, device=dev)
+        if pipeline == 2:
+            vv = [(d[sl], a[sl], st) for sl, st in venv.pipeline_halves()]
+
+            def body():
+                for dd, aa, st in vv:
+                    with torch.cuda.stream(st):
+                        torch.sign(dd, out=aa)
+                venv.step(a)
+        else:
+            def body():
+                torch.sign(d, out=a)
+                venv.step(a)
+        for _ in range(EPISODE):
+            body()
+        venv.join()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(2 * EPISODE):
+            body()
+        venv.join()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / (2 * EPISODE)
+        venv.close()
+        out[f'vector_env_api_pipeline{pipeline}'] = {
+            'workload': f'{N} x 54-station (caltech) EVChargingVectorEnv.step(output=torch, pipeline={pipeline}), DeviceGMMTraceGenerator, '
+                        'greedy computed by the caller from obs[demands], two episodes incl. boundaries',
+            'ms_per_step': round(dt * 1e3, 5), 'env_steps_per_s': round(N / dt, 1)}
+    out['workload'] = f'{N} x {n}-station (caltech), synthetic days, projection on, staggered phases; policy reads the step\'s observation'
     return out
 
 
@@ -862,6 +966,9 @@ def main():
                          ('rollout_greedy_65536', lambda: secondary_rollout('greedy', local_rank, args.battery)),
                          ('rollout_random_65536', lambda: secondary_rollout('random', local_rank, args.battery)),
                          ('rollout_random_65536_gmm', lambda: secondary_rollout('random', local_rank, args.battery, 'gmm')),
+                         ('rollout_greedy_65536_gmm', lambda: secondary_rollout('greedy', local_rank, args.battery, 'gmm')),
+                         ('rollout_greedy_65536_jpl_gmm', lambda: secondary_rollout('greedy', local_rank, args.battery, 'gmm', 'jpl')),
+                         ('closed_loop_65536', lambda: secondary_closed_loop(local_rank, args.battery)),
                          ('vector_env_api', lambda: secondary_vector_env_api(local_rank, args.battery)),
                          ('rccl_world1', secondary_rccl_world1),
                          ('multiagent_8192x54', lambda: secondary_multiagent(local_rank, args.battery)),

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 4
+#define EVC_ABI_VERSION 5
 
 #define EVC_MAX_STATIONS     64   /* one gfx950 wavefront per environment            */
 #define EVC_MAX_CONSTRAINTS  32   /* rows of ChargingNetwork.constraint_matrix       */
@@ -165,6 +165,14 @@ int evc_synchronize(evc_engine* e);
 int evc_set_pipeline(evc_engine* e, int32_t halves);
 /* The engine's stream waits for the pending half launches (no-op when there are none). */
 int evc_join(evc_engine* e);
+/* Closed loop under the pipelined mode (a policy that READS the observation of step k to produce the action of step
+ * k + 1, train_stable_baselines.py:271-275): half h (0 | 1) steps environments [*env_lo, *env_hi) on the internal stream
+ * *hip_stream.  Work the caller enqueues on THAT stream — its policy for those environments: reads rows
+ * [env_lo, env_hi) of the previous step's outputs, writes the same rows of the action buffer — is ordered after the
+ * half's previous launch and before its next one by the stream itself, so the policy of one half runs under the other
+ * half's step and no join is needed between steps.  Rows of the other half must not be touched from this stream.
+ * Valid after evc_set_pipeline(e, 2); the streams live as long as the engine. */
+int evc_pipeline_half(evc_engine* e, int32_t half, void** hip_stream, int32_t* env_lo, int32_t* env_hi);
 /* How many steps of this engine ran as two half launches so far, and (ordered, may be NULL) how many of those found
  * work pending on the engine's stream and were ordered behind it with an event (diagnostics, tests). */
 int evc_pipelined_steps(evc_engine* e, uint64_t* count, uint64_t* ordered);

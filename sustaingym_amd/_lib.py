@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SUSTAINGYM_AMD_LIB', os.path.join(_PKG, 'libevcharge_hip.so'))
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'evcharge.h')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_STATIONS, MAX_CONSTRAINTS, MAX_GROUPS, MAX_SESSIONS = 64, 32, 16, 256
 MOER_ROWS, MOER_COLS, EPISODE_STEPS = 289, 37, 288
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     'evc_synchronize': (_i32, [_vp]),
     'evc_set_pipeline': (_i32, [_vp, _i32]),
     'evc_join': (_i32, [_vp]),
+    'evc_pipeline_half': (_i32, [_vp, _i32, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32)]),
     'evc_obs_dim': (_i32, [_vp]),
     'evc_num_envs': (_i32, [_vp]),
     'evc_num_stations': (_i32, [_vp]),

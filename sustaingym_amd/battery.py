@@ -44,7 +44,11 @@ class BatteryDispatchVectorEnv:
     """N independent battery-dispatch environments stepped by one kernel launch.
 
     ``reset(slots=None) -> obs[N, 4k+6]``; ``step(bids[N, 2k]) -> (obs, reward[N], terminated[N])``;
-    numpy in / numpy out (host staging) or CUDA tensors in / out (``output='torch'``)."""
+    numpy in / numpy out (host staging; fresh arrays every call) or CUDA tensors in / out (``output='torch'``).
+
+    With ``output='torch'`` the three tensors returned by ``reset`` / ``step`` are the environment's PERSISTENT device
+    buffers — the same ``obs``, ``reward`` and ``terminated`` (bool) objects every call, overwritten by the next step on
+    the stream the call was issued on: a caller that keeps a step's values clones them."""
 
     def __init__(self, num_envs: int, forecast_steps: int = 36, bank_slots: int | None = None, device: int = 0,
                  capacity_mwh: float = 80.0, max_power_mw: float = 20.0, eta_charge: float = 0.95,

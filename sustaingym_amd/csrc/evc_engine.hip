@@ -125,7 +125,7 @@ struct evc_engine {
     int pipeline = 1;
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
-    bool halves_pending = false, side_warmed = false, last_split = false;
+    bool halves_pending = false, side_warmed = false, last_split = false, side_ready = false;
     unsigned train_len = 0, prev_train_len = 0;   // pipelined steps since the last join, and in the train before it
     unsigned long long split_steps = 0;   // steps that ran as two half launches (evc_pipelined_steps) ...
     unsigned long long fork_steps = 0;    // ... and how many of them had to be ordered behind pending work of the engine's stream
@@ -397,6 +397,11 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     io.action_kind = action_kind == EVC_ACTION_GREEDY ? EVC_ACTION_GREEDY : EVC_ACTION_F32;
     io.bins = 0;
     io.out = *out;
+    // The staged action kinds run a kernel on the engine's stream before the step (random_actions_kernel reads the
+    // environments' scalars): it must not overtake half launches still pending on the side streams.  Such steps are
+    // never split themselves (below).
+    if (action_kind != EVC_ACTION_F32)
+        if (int rc = join_halves(e)) return rc;
     if (action_kind == EVC_ACTION_DISCRETE) {
         const size_t count = (size_t)e->P.N * e->P.n;
         if (!e->d_act_f32) HIP_TRY(dmalloc(&e->d_act_f32, count));
@@ -709,6 +714,7 @@ int launch_rollout(evc_engine* e, const void* actions_dev, int ring_len, int act
     if (e->timing) {
         e->ev_valid = true;
         e->ev_slow = false;
+        e->ev_split = false;                         // ev[4], ev[5] belong to an earlier pipelined step
     }
     HIP_TRY(hipGetLastError());
     e->env_steps += (unsigned long long)e->P.N * (unsigned long long)steps;
@@ -920,17 +926,19 @@ int evc_set_pipeline(evc_engine* e, int32_t halves) {
     if (!e) return fail(EVC_EINVAL, "null engine");
     if (halves != 1 && halves != 2) return fail(EVC_EINVAL, "evc_set_pipeline: halves must be 1 or 2, got %d", halves);
     if (int rc = bind(e)) return rc;
-    if (halves == 2 && !e->fork_ev) {
-        HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
+    if (halves == 2 && !e->side_ready) {
+        // each object is created once: a call that failed half way is resumed, not skipped, by the next one
+        if (!e->fork_ev) HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
         for (int h = 0; h < 2; h++) {
-            HIP_TRY(hipEventCreateWithFlags(&e->join_ev[h], hipEventDisableTiming));
-            HIP_TRY(hipStreamCreateWithFlags(&e->side[h], hipStreamNonBlocking));
+            if (!e->join_ev[h]) HIP_TRY(hipEventCreateWithFlags(&e->join_ev[h], hipEventDisableTiming));
+            if (!e->side[h]) HIP_TRY(hipStreamCreateWithFlags(&e->side[h], hipStreamNonBlocking));
         }
         // a HIP stream gets its hardware queue at its first launch (milliseconds): here, not inside somebody's timed loop
         for (int h = 0; h < 2; h++) {
             hipLaunchKernelGGL(side_stream_warmup_kernel, dim3(1), dim3(64), 0, e->side[h]);
             HIP_TRY(hipStreamSynchronize(e->side[h]));
         }
+        e->side_ready = true;
     }
     e->pipeline = halves;
     return EVC_OK;
@@ -939,6 +947,17 @@ int evc_set_pipeline(evc_engine* e, int32_t halves) {
 int evc_join(evc_engine* e) {
     if (!e) return fail(EVC_EINVAL, "null engine");
     return bind(e);
+}
+
+int evc_pipeline_half(evc_engine* e, int32_t half, void** hip_stream, int32_t* env_lo, int32_t* env_hi) {
+    if (!e || !hip_stream || !env_lo || !env_hi) return fail(EVC_EINVAL, "evc_pipeline_half: null argument");
+    if (half != 0 && half != 1) return fail(EVC_EINVAL, "evc_pipeline_half: half must be 0 or 1, got %d", half);
+    if (!e->side_ready) return fail(EVC_ESTATE, "evc_pipeline_half: call evc_set_pipeline(e, 2) first");
+    const int nq = (e->P.N + 3) / 4, mid = (nq / 2) & ~7;      // the split of launch_split
+    *hip_stream = (void*)e->side[half];
+    *env_lo = half ? mid * 4 : 0;
+    *env_hi = half ? e->P.N : mid * 4;
+    return EVC_OK;
 }
 
 int evc_pipelined_steps(evc_engine* e, uint64_t* count, uint64_t* ordered) {
@@ -1175,7 +1194,7 @@ int evc_rollout(evc_engine* e, const void* actions_dev, int32_t action_kind, int
             ? nullptr : (const void*)((const char*)actions_dev + (size_t)(i % ring_len) * stride);
         if (int rc = launch_step(e, a, action_kind, bins, out)) return rc;
     }
-    return EVC_OK;
+    return join_halves(e);                        // like every entry point but evc_step: complete on the engine's stream
 }
 
 int evc_last_rollout_waves(evc_engine* e, int32_t* waves) {
@@ -1257,6 +1276,7 @@ int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, 
     od.projected = oh->projected ? e->d_proj : nullptr;
     od.returns = nullptr;
     if (int rc = launch_step(e, e->d_act, action_kind, bins, &od)) return rc;
+    if (int rc = join_halves(e)) return rc;       // a pipelined step leaves two half launches on the side streams
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (oh->obs) HIP_TRY(copy_d2h(oh->obs, e->d_obs, sizeof(float) * N * F, e->stream));
     if (oh->reward) HIP_TRY(copy_d2h(oh->reward, e->d_reward, sizeof(double) * N, e->stream));

@@ -348,8 +348,16 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                 for (int c = 0; c < kSlots; c++) st_gid[c] = valid[c] ? (int)(st_info[st[c]] & 0x7fu) : -1;
                 unsigned cap_viol;
                 bool anyviol;
-                // only class caps left open by the screen on a network with monotone rows: cap those classes, nothing else
-                // to evaluate (evc_cquad.h, "Shortcut")
+                // Caps-only shortcut (this kernel only; measured and not adopted in step_kernel_cquad):
+                // where the screen left only simple rows (class caps) open on a network whose rows are monotone in every
+                // class sum (Params::monotone_rows), capping those classes IS the projection and no row is evaluated again.
+                // Why the second quad_exact_rows check of the step kernels can be dropped here: (i) a capped class ends at
+                // its cap up to the water-filling's tolerance plus the tie snap, at most n_g * 2^-17 A — exactly the slack
+                // Params::snap_tol is derived from, so that check passes by construction; (ii) every other row was cleared
+                // by the screen at the box-clipped point on class sums of ceil(8 y) / 8, the capping only lowers class sums
+                // (monotone rows stay cleared), and the snap moves a value by < 2^-16 A where the screen's thresholds keep
+                // the float32 error of a whole row in hand.  The equivalence with a loop of evc_step calls is tested with
+                // the shortcut on and off (tests/test_gpu_rollout.py::test_caps_shortcut_on_and_off...).
                 const unsigned open_rows = (unsigned)(__ballot(maybe) >> (row * 16u)) & 0xffffu;
                 const bool caps_only = S.rare.monotone_rows != 0 && (open_rows & ~S.rare.simple_rows) == 0u;
                 const bool shortcut = __ballot(undecided && !caps_only) == 0ull;

@@ -399,6 +399,19 @@ class StepEngine:
         check(self.lib.evc_set_pipeline(self.handle, int(halves)), 'evc_set_pipeline')
         self._pipeline = int(halves)
 
+    def pipeline_halves(self):
+        """Closed loop under ``set_pipeline(2)`` (``evc_pipeline_half``): ``[(slice, torch.cuda.ExternalStream), ...]`` for the
+        two half batches.  A policy for half h — reading rows ``sl`` of the previous step's outputs, writing rows ``sl`` of
+        the action tensor — enqueued under ``with torch.cuda.stream(stream):`` runs after that half's previous launch and
+        before its next one, under the OTHER half's step; no ``join()`` between steps."""
+        torch = self._torch()
+        halves = []
+        for h in range(2):
+            st, lo, hi = C.c_void_p(), C.c_int32(), C.c_int32()
+            check(self.lib.evc_pipeline_half(self.handle, h, C.byref(st), C.byref(lo), C.byref(hi)), 'evc_pipeline_half')
+            halves.append((slice(lo.value, hi.value), torch.cuda.ExternalStream(st.value, device=torch.device('cuda', self.device))))
+        return halves
+
     def join(self) -> None:
         """Orders the engine's (torch) stream after the pending half launches of the pipelined mode."""
         check(self.lib.evc_join(self.handle), 'evc_join')

@@ -355,14 +355,29 @@ class EVChargingVectorEnv(_VectorEnvBase):
     hands out the engine's two alternating page-locked buffer sets (valid until the step after the next
     one; what SB3VecEnv, which copies anyway, and throughput measurements use).  ``'torch'`` takes and
     returns device tensors without leaving the GPU; those ARE the engine's output buffers and are
-    overwritten by the next step (clone what must be kept)."""
+    overwritten by the next step (clone what must be kept).
+
+    ``pipeline=2`` (``output='torch'`` only; opt-in, changes the ordering contract): float32 steps run as two
+    half-batch launches on two internal streams (``evc_set_pipeline``) and ``step()`` does NOT order the caller's
+    stream after them.  A closed-loop policy keeps the overlap by computing each half's actions on that half's stream::
+
+        halves = venv.pipeline_halves()                  # [(slice, torch.cuda.ExternalStream)] x 2
+        for sl, stream in halves:
+            with torch.cuda.stream(stream):
+                actions[sl] = policy(obs['demands'][sl])  # rows of this half only
+        obs, rew, term, trunc, info = venv.step(actions)
+
+    so that the policy of one half runs under the other half's step; ``venv.join()`` orders the current stream after
+    both halves (before reading a whole-batch output there)."""
 
     def __init__(self, data_generators: Sequence[AbstractTraceGenerator] | Callable[[int], AbstractTraceGenerator],
                  num_envs: int | None = None, moer_forecast_steps: int = 36,
                  project_action_in_env: bool = True, discrete_bins: int = -1, device: int = 0,
                  output: str = 'numpy', max_sessions: int = 128, charge_calculation: str = 'continuous',
-                 zero_copy: bool = False):
+                 zero_copy: bool = False, pipeline: int = 1):
         assert output in ('numpy', 'torch')
+        assert pipeline in (1, 2) and (pipeline == 1 or output == 'torch'), 'pipeline=2 needs output="torch"'
+        self.pipeline = int(pipeline)
         self.zero_copy = bool(zero_copy)
         self._batched = data_generators if isinstance(data_generators, BatchedGMMTraceGenerator) else None
         self._devgen = data_generators if isinstance(data_generators, DeviceGMMTraceGenerator) else None
@@ -410,6 +425,8 @@ class EVChargingVectorEnv(_VectorEnvBase):
         moer = np.stack([g0.moer_loader.retrieve(self._day0 + timedelta(days=d)) for d in range(self._ndays)])
         self._engine.upload_moer(moer, 0)
         self._engine.set_autoreset_stride(1 if self._realbank is not None else N)
+        if self.pipeline == 2:
+            self._engine.set_pipeline(2)
         if self._devgen is not None:
             self._engine.upload_gmm(self._devgen.tables)
         if self._realbank is not None:                 # the whole period, once
@@ -502,6 +519,14 @@ class EVChargingVectorEnv(_VectorEnvBase):
             day[j] = (g.day - self._day0).days         # MOER of the advanced day (env.py:321-323)
             self._max_profit[slots[j]] = table.max_profit()
         self._upload_runs(np.asarray(slots), ns, sess, req, day)
+
+    def pipeline_halves(self):
+        """``[(slice of environments, torch.cuda.ExternalStream)]`` of the two half batches (``pipeline=2``)."""
+        return self._engine.pipeline_halves()
+
+    def join(self) -> None:
+        """Orders the current torch stream after the pending half launches (no-op with ``pipeline=1``)."""
+        self._engine.join()
 
     def _wrap_obs(self, flat):
         return {key: flat[:, sl] for key, sl in self._slices.items()}
@@ -696,9 +721,9 @@ class SB3VecEnv(_SB3VecEnvBase):
     def __init__(self, venv: EVChargingVectorEnv):
         assert venv.output == 'numpy'
         self.venv = venv
-        # this adapter copies every array it hands out (SB3's rollout buffer keeps references across steps), so the
-        # vector env underneath may hand out its alternating page-locked buffers instead of copying a first time
-        venv.zero_copy = True
+        # this adapter copies every array it hands out (SB3's rollout buffer keeps references across steps), so on ITS
+        # calls the vector env underneath may hand out its alternating page-locked buffers instead of copying a first
+        # time (step_wait); the caller's venv object itself is left as it was configured
         if _SB3VecEnvBase is not object:       # sets num_envs / spaces, queries get_attr('render_mode')
             super().__init__(venv.num_envs, venv.single_observation_space, venv.single_action_space)
         self.num_envs = venv.num_envs
@@ -722,7 +747,12 @@ class SB3VecEnv(_SB3VecEnvBase):
         self._actions = actions
 
     def step_wait(self):
-        obs, rew, term, trunc, info = self.venv.step(self._actions)
+        keep = self.venv.zero_copy
+        self.venv.zero_copy = True                 # for this call only: everything handed out below is copied here
+        try:
+            obs, rew, term, trunc, info = self.venv.step(self._actions)
+        finally:
+            self.venv.zero_copy = keep
         infos: list[dict[str, Any]] = []
         bd = info['reward_breakdown']
         for i in range(self.num_envs):

@@ -151,3 +151,84 @@ def test_rollout_as_a_loop_of_steps_is_pipelined_too(monkeypatch):
     _assert_same(_state(one), _state(two), 'after the looped rollout')
     one.close()
     two.close()
+
+
+def test_host_step_waits_for_both_halves(monkeypatch):
+    """evc_step_host after evc_set_pipeline(2) splits its launch like evc_step does; the copies back to
+    the host must wait for BOTH half launches (they run on side streams the engine's stream does not see by itself), and a
+    device-policy step (random actions: a kernel on the engine's stream that reads the environments' scalars) issued while
+    halves are pending must be ordered behind them.  Host outputs of 40 pipelined numpy steps == the single-launch
+    engine's, step by step, from pinned and from pageable action arrays."""
+    import torch
+    from sustaingym_amd.network import caltech_acn
+    monkeypatch.setenv('EVC_DRAIN', '1')
+    net = caltech_acn()
+    n = net.num_stations
+    wl = make_workload(net, N, bank_slots=512, seed=14, moer_days=3)
+    one, two = _engine(net, wl, True, 1), _engine(net, wl, True, 2)
+    assert np.array_equal(one.reset(host=True), two.reset(host=True))
+    rng = np.random.default_rng(6)
+    pinned = torch.empty((N, n), dtype=torch.float32).pin_memory().numpy()
+    for t in range(40):
+        a = rng.random((N, n), dtype=np.float32)
+        if t % 2:
+            pinned[:] = a
+            a = pinned                                    # page-locked: the h2d copy leaves the engine's stream idle at once
+        g1 = {k: v.copy() for k, v in one.step(a).items()}
+        g2 = {k: v.copy() for k, v in two.step(a).items()}
+        for k in g1:
+            assert np.array_equal(g1[k], g2[k]), (t, k)
+    assert two.pipelined_steps() == 40 and one.pipelined_steps() == 0
+    # pipelined device steps left pending, then a random-policy step: its action kernel reads t / episode of every environment
+    for eng in (one, two):
+        eng.set_policy_seed(5, env_id_base=0)
+    dev = to_device(rng.random((N, n), dtype=np.float32))
+    s1, _ = one.make_stepper()
+    s2, _ = two.make_stepper()
+    for t in range(6):
+        s1(dev.data_ptr())
+        s2(dev.data_ptr())
+    r1 = {k: np.array(v) for k, v in one.step_policy('random').items()}
+    r2 = {k: np.array(v) for k, v in two.step_policy('random').items()}
+    for k in r1:
+        assert np.array_equal(r1[k], r2[k]), k
+    _assert_same(_state(one), _state(two), 'after host steps and a random-policy step')
+    one.close()
+    two.close()
+
+
+def test_closed_loop_with_per_half_policies_equals_the_single_launch(monkeypatch):
+    """evc_pipeline_half: a policy that reads the step's observation (the caller's greedy, sign(demands)), enqueued per
+    half on that half's stream, under pipelined steps WITHOUT any join — 300 steps across the autoreset boundary leave
+    the state and outputs of the same closed loop run as one launch per step on one stream."""
+    import torch
+    from sustaingym_amd.network import caltech_acn
+    monkeypatch.setenv('EVC_DRAIN', '1')
+    net = caltech_acn()
+    n = net.num_stations
+    wl = make_workload(net, N, bank_slots=1024, seed=17, busy=True, moer_days=4)
+    one, two = _engine(net, wl, True, 1), _engine(net, wl, True, 2)
+    assert np.array_equal(to_host(one.reset()), to_host(two.reset()))
+    s1, o1 = one.make_stepper()
+    s2, o2 = two.make_stepper()
+    a1 = torch.zeros((N, n), dtype=torch.float32, device='cuda')
+    a2 = torch.zeros((N, n), dtype=torch.float32, device='cuda')
+    halves = two.pipeline_halves()
+    assert halves[0][0].start == 0 and halves[0][0].stop == halves[1][0].start and halves[1][0].stop == N
+    torch.cuda.synchronize()
+    for t in range(300):
+        torch.sign(o1['obs'][:, :n], out=a1)
+        s1(a1.data_ptr())
+        for sl, st in halves:
+            with torch.cuda.stream(st):
+                torch.sign(o2['obs'][sl, :n], out=a2[sl])
+        s2(a2.data_ptr())
+    assert two.pipelined_steps(ordered=True) == (300, 0)          # every step split, none had to wait for the engine's stream
+    two.join()
+    torch.cuda.synchronize()
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    assert torch.equal(a1, a2)
+    _assert_same(_state(one), _state(two), 'closed loop')
+    one.close()
+    two.close()

@@ -256,3 +256,28 @@ def test_both_register_budgets_of_the_rollout_kernel_give_the_same_day():
                 assert np.array_equal(first[k], got[k], equal_nan=True), (rep, k, eng.last_rollout_waves())
     assert seen == {2, 3}, seen
     eng.close()
+
+
+@pytest.mark.parametrize('site', ['caltech', 'jpl'])
+def test_caps_shortcut_on_and_off_leave_the_same_state(site, monkeypatch):
+    """the fused kernel's caps-only shortcut skips the second evaluation of the rows.  A congested bank (GMM days
+    under the greedy policy: pods bind in most periods) played with the shortcut and without it (EVC_CAPS_SHORTCUT=0: every
+    undecided environment goes through quad_exact_rows twice like in the step kernels): every piece of state and every
+    output bit for bit, no projection flagged as not converged."""
+    N = 2048
+    period = 'Summer 2019' if site == 'caltech' else 'Summer 2021'
+    res = []
+    for shortcut in ('1', '0'):
+        monkeypatch.setenv('EVC_CAPS_SHORTCUT', shortcut)
+        net, eng = _gmm_engine(site, period, N, N, seed=31, autoreset=True)
+        eng.set_autoreset_stride(N)
+        eng.reset()
+        out = _run(eng, 'greedy', 288, 0, True)
+        res.append((out, eng.get_state()))
+        eng.close()
+    (a, sa), (b, sb) = res
+    for k in ('scalars', 'departure', 'est_departure', 'remaining_kwh', 'breakdown'):
+        assert np.array_equal(sa[k], sb[k]), (site, k)
+    for k in ('obs', 'reward', 'terminated', 'breakdown', 'returns', 'final_obs'):
+        assert np.array_equal(a[k], b[k]), (site, k)
+    assert not (sa['scalars'][:, 6] & 2).any()

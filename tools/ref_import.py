@@ -111,6 +111,117 @@ def install_stubs() -> None:
     du.read_bytes = read_bytes
 
 
+def install_step_stubs() -> None:
+    """Container-only stubs that let the PYTHON HALF of the step import unmodified:
+    ``sustaingym.envs.evcharging.env`` (EVChargingEnv: class constants env.py:99-114, ``__init__`` :116-176,
+    ``_to_schedule`` :340-379, ``_get_observation`` :381-394, ``_get_reward`` :431-464),
+    ``sustaingym.envs.wrappers`` (DiscreteActionWrapper.action :43-45) and
+    ``sustaingym.envs.evcharging.multiagent_env`` (``_create_dict_from_obs_agg`` :102-148).
+
+    What is stubbed are base classes and containers, NOT arithmetic:
+    * ``gymnasium.Env`` / ``ActionWrapper`` / ``pettingzoo.ParallelEnv``: empty subscriptable base classes
+      (``ActionWrapper.__init__`` stores ``env``; ``ParallelEnv.num_agents`` = ``len(self.agents)``);
+    * ``gymnasium.spaces.Box / Dict / Discrete / MultiDiscrete``: attribute bags; ``Dict`` keeps its sub-spaces in SORTED
+      key order and ``spaces.flatten`` concatenates the raveled values in that order — gymnasium 0.28's behaviour for a
+      plain-dict Dict space, restated from memory ([MEM]: gymnasium is not in the image).  That ordering is the one thing
+      here that is not a pure container; it moves no number;
+    * ``cvxpy``: importable, every attribute raises if it is touched (the projection cannot run here);
+    * the simulator / interface / network objects the env methods read are supplied by the caller
+      (tests/golden/make_step_unit_golden.py) as attribute bags whose values are FIXTURE INPUTS."""
+    install_stubs()
+    if 'gymnasium.spaces' in sys.modules:
+        return
+    import collections
+    import typing
+
+    import numpy as np
+
+    class _Generic:
+        def __class_getitem__(cls, item):
+            return cls
+
+    gym = sys.modules['gymnasium']
+
+    class Env(_Generic):
+        def reset(self, *, seed=None, options=None):
+            return None
+
+    class ActionWrapper(_Generic):
+        def __init__(self, env):
+            self.env = env
+
+    spaces = types.ModuleType('gymnasium.spaces')
+
+    class Box(_Bag):
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            super().__init__(low=low, high=high, shape=tuple(shape) if shape is not None else (), dtype=np.dtype(dtype))
+
+    class Dict(_Bag):
+        def __init__(self, spaces_):
+            super().__init__(spaces=collections.OrderedDict(sorted(spaces_.items())))
+
+        def __getitem__(self, k):
+            return self.spaces[k]
+
+        def keys(self):
+            return self.spaces.keys()
+
+    class Discrete(_Bag):
+        def __init__(self, n):
+            super().__init__(n=int(n), shape=(), dtype=np.dtype(np.int64))
+
+    class MultiDiscrete(_Bag):
+        def __init__(self, nvec):
+            super().__init__(nvec=np.asarray(nvec), shape=np.asarray(nvec).shape, dtype=np.dtype(np.int64))
+
+    def flatten(space, x):
+        if isinstance(space, Dict):
+            return np.concatenate([np.asarray(x[k], dtype=space[k].dtype).ravel() for k in space.keys()])
+        return np.asarray(x, dtype=space.dtype).ravel()
+
+    def flatten_space(space):
+        if isinstance(space, Dict):
+            size = sum(int(np.prod(s.shape)) for s in space.spaces.values())
+            return Box(None, None, shape=(size,), dtype=np.float32)
+        return Box(space.low, space.high, shape=(int(np.prod(space.shape)),), dtype=space.dtype)
+
+    spaces.Box, spaces.Dict, spaces.Discrete, spaces.MultiDiscrete = Box, Dict, Discrete, MultiDiscrete
+    spaces.Space = _Bag
+    spaces.flatten, spaces.flatten_space = flatten, flatten_space
+    core = types.ModuleType('gymnasium.core')
+    core.ObsType = typing.TypeVar('ObsType')
+    gym.Env, gym.ActionWrapper, gym.spaces, gym.core = Env, ActionWrapper, spaces, core
+    sys.modules.update({'gymnasium.spaces': spaces, 'gymnasium.core': core})
+
+    pz = types.ModuleType('pettingzoo')
+
+    class ParallelEnv(_Generic):
+        @property
+        def num_agents(self):
+            return len(self.agents)
+
+    pz.ParallelEnv = ParallelEnv
+    sys.modules['pettingzoo'] = pz
+
+    class _Untouchable(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            raise RuntimeError(f'cvxpy.{name}: cvxpy is not in this image; the projection cannot run here')
+
+    sys.modules['cvxpy'] = _Untouchable('cvxpy')
+
+
+def reference_step_modules():
+    """Returns the reference modules (env, wrappers, multiagent_env), imported unmodified from /root/reference."""
+    install_step_stubs()
+    import importlib
+    env = importlib.import_module('sustaingym.envs.evcharging.env')
+    wr = importlib.import_module('sustaingym.envs.wrappers')
+    ma = importlib.import_module('sustaingym.envs.evcharging.multiagent_env')
+    return env, wr, ma
+
+
 def reference_generators():
     """Returns the reference modules (event_generation, utils, load_moer)."""
     install_stubs()
