@@ -572,33 +572,66 @@ def secondary_closed_loop(dev_index, battery) -> dict:
         dt = (time.perf_counter() - t0) / steps
         return {'ms_per_step': round(dt * 1e3, 5), 'env_steps_per_s': round(N / dt, 1), 'host_issue_us_per_step': round(host * 1e6, 2)}
 
-    def single():
-        torch.sign(demands, out=acts)                 # greedy by the caller: reads this step's observation
-        w.step(ptr)
-    out['single_launch'] = dict(timed(single), form='one launch per step; policy = torch.sign(obs[:, :n], out=actions) on the engine stream')
-    out['open_loop_single_launch'] = timed(lambda: w.step(ptr))
+    # Two policies, one torch kernel each: 'min_u' = min(demands, u) with u the headline's U[0,1) action ring — a true function
+    # of the observation whose values equal the headline's wherever an EV still wants more than 1 kWh, so the WORKLOAD is the
+    # headline's and the difference to the open loop is the loop itself; 'greedy' = sign(demands), the reference's
+    # GreedyAlgorithm computed by the caller (baselines.py:32-35) — every EV asks for 32 A, pods bind in most periods: a
+    # heavier workload, listed for what it is.
+    ring = w.ring
+    state = {'i': 0}
+
+    ring_views = {None: ring}
+
+    def policy(kind, d, a, sl=None):
+        if kind == 'greedy':
+            torch.sign(d, out=a)
+        else:
+            rv = ring_views[sl]
+            torch.minimum(d, rv[state['i'] % len(rv)], out=a)
+
+    halves = None
+    for kind in ('min_u', 'greedy'):
+        rec = {}
+        eng.set_pipeline(1)
+
+        def single():
+            policy(kind, demands, acts)
+            w.step(ptr)
+            state['i'] += 1
+        rec['single_launch'] = dict(timed(single), form='one launch per step, policy on the engine stream')
+        eng.set_pipeline(2)
+        if halves is None:
+            halves = eng.pipeline_halves()
+            views = [(demands[sl], acts[sl], h, st) for h, (sl, st) in enumerate(halves)]
+            for h, (sl, st) in enumerate(halves):
+                ring_views[h] = [r[sl] for r in ring]          # views built once: the loop below is host-bound otherwise
+            main_stream = torch.cuda.current_stream(dev)
+
+        def joined():
+            policy(kind, demands, acts)
+            w.step(ptr)
+            eng.join()
+            state['i'] += 1
+        rec['pipelined_joined'] = dict(timed(joined, steps=192), form='two half launches per step, evc_join after every step, policy on the engine stream')
+
+        def per_half():
+            for d, a, h, st in views:
+                torch.cuda.set_stream(st)            # (the `with torch.cuda.stream(...)` form costs ~6 us of host time more per half)
+                policy(kind, d, a, h)
+            torch.cuda.set_stream(main_stream)
+            w.step(ptr)
+            state['i'] += 1
+        before = eng.pipelined_steps(ordered=True)
+        rec['pipelined_per_half_policy'] = dict(timed(per_half), form='two half launches per step, each half\'s policy enqueued on that '
+                                                'half\'s stream (evc_pipeline_half): no join, no fork event')
+        after = eng.pipelined_steps(ordered=True)
+        rec['pipelined_per_half_policy']['pipelined_steps'] = int(after[0] - before[0])
+        rec['pipelined_per_half_policy']['steps_ordered_behind_the_engine_stream'] = int(after[1] - before[1])
+        out['policy_' + kind] = rec
+    eng.set_pipeline(1)
+    out['open_loop_single_launch'] = timed(lambda: w.step(w.ptrs[0]))
     eng.set_pipeline(2)
-
-    def joined():
-        torch.sign(demands, out=acts)
-        w.step(ptr)
-        eng.join()
-    out['pipelined_joined'] = dict(timed(joined), form='two half launches per step, evc_join after every step, policy on the engine stream')
-    halves = eng.pipeline_halves()
-    views = [(demands[sl], acts[sl], st) for sl, st in halves]
-
-    def per_half():
-        for d, a, st in views:
-            with torch.cuda.stream(st):
-                torch.sign(d, out=a)
-        w.step(ptr)
-    before = eng.pipelined_steps(ordered=True)
-    out['pipelined_per_half_policy'] = dict(timed(per_half), form='two half launches per step, each half\'s policy enqueued on that '
-                                            'half\'s stream (evc_pipeline_half): no join, no fork event')
-    after = eng.pipelined_steps(ordered=True)
-    out['pipelined_per_half_policy']['pipelined_steps'] = int(after[0] - before[0])
-    out['pipelined_per_half_policy']['steps_ordered_behind_the_engine_stream'] = int(after[1] - before[1])
-    out['open_loop_pipelined'] = timed(lambda: w.step(ptr))
+    out['open_loop_pipelined'] = timed(lambda: w.step(w.ptrs[0]))
     w.close()
 
     # the API north_star names, on the reference's own episode distribution

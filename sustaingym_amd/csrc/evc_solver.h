@@ -541,8 +541,11 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
             }
         }
 #ifndef EVC_ABL_NO_WAVE_CONE
-        else {
-            // (c) one or two cone rows decide: registers only, see wave_cone; exact if every row and cap holds at the optimum
+        if (!settled) {
+            // (c) one to three rows decide: registers only, see wave_cone; exact if every row holds at the optimum.  A class
+            // cap is a row like any other here (its own simple row of the matrix), so the chain also takes the environments
+            // the water-filling left with a feeder row violated beside their pod caps (round 4: those went to the general
+            // iteration below — ~84 000 cycles for 7 iterations on 2.6 rows, the tail of every congested Caltech step).
             const int r1[1] = {e0.worst};
             double z1[2] = {0.0, 0.0}, y1 = 0.0;
             if (wave_cone<1>(L.net, lnet.gid, ln.b, ln.h, r1, z1, y1)) {
@@ -550,7 +553,7 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
                 if (e1.viol == 0ull && e1.cap_viol == 0u) {
                     ln.y = y1;
                     settled = true;
-                } else if (e1.cap_viol == 0u && e1.worst != e0.worst) {
+                } else if (e1.viol != 0ull && e1.worst != e0.worst) {
                     const int r2[2] = {e0.worst, e1.worst};
                     double z2[4] = {z1[0], z1[1], 0.0, 0.0}, y2 = 0.0;
                     if (wave_cone<2>(L.net, lnet.gid, ln.b, ln.h, r2, z2, y2)) {
@@ -558,7 +561,7 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
                         if (e2.viol == 0ull && e2.cap_viol == 0u) {
                             ln.y = y2;
                             settled = true;
-                        } else if (e2.cap_viol == 0u && e2.worst != r2[0] && e2.worst != r2[1]) {
+                        } else if (e2.viol != 0ull && e2.worst != r2[0] && e2.worst != r2[1]) {
                             // a third row: rare, but one such environment per step is what the whole launch waits for
                             const int r3[3] = {r2[0], r2[1], e2.worst};
                             double z3[6] = {z2[0], z2[1], z2[2], z2[3], 0.0, 0.0}, y3 = 0.0;
