@@ -25,6 +25,7 @@
 #pragma once
 
 #include "evc_cquad.h"
+#include "evc_rowcone.h"
 #include "evc_rollout_launch.h"
 
 namespace evc {
@@ -63,8 +64,41 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
     typedef __attribute__((address_space(3))) RolloutLds LdsImage;
     RolloutLds& S = *(RolloutLds*)(LdsImage*)(size_t)(unsigned)rfl((int)lds);
     const int w = rfl((int)wv);
-    const unsigned mask = (unsigned)rfl((int)rows);
+    unsigned mask = (unsigned)rfl((int)rows);
     const int lane = (int)__lane_id();
+#ifndef EVC_NO_ROWCONE             /* variant builds only: the round-3 form (every row through the wave-per-environment solver) */
+    {
+        // Round 4: all flagged rows at once, each in its own 16-lane row (evc_rowcone.h): box clip -> caps -> one cone row -> two.
+        // What that settles is written back and taken out of `mask`; the general path below only sees what is left.
+        const unsigned q = (unsigned)lane & 15u, row = (unsigned)lane >> 4;
+        const bool on = ((mask >> row) & 1u) != 0u;
+        int st_gid[kSlots];
+        bool is_cc[kSlots];
+        double b[kSlots], h[kSlots], y[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const unsigned st = (unsigned)j * 16u + q;
+            const bool valid = st < (unsigned)P.n;
+            const unsigned info = S.st_info[st];
+            st_gid[j] = valid ? (int)(info & 0x7fu) : -1;
+            is_cc[j] = (info >> 7) != 0u;
+            h[j] = valid ? S.img[w][row][st].h_or_y : 0.0;
+            b[j] = !valid ? 0.0 : (mask & 16u) ? (double)S.act_img[w][row][st] * Consts::ACTION_SCALE_FACTOR : Consts::ACTION_SCALE_FACTOR;
+        }
+        const bool settled = quad_project(S.rare.G, S.rare.class_cap, P.tie_counters, S.net, q, (unsigned)P.m, row, on, st_gid, is_cc, b, h, y);
+        if (settled) {
+#pragma unroll
+            for (int j = 0; j < kSlots; j++)
+                if (st_gid[j] >= 0) S.img[w][row][(unsigned)j * 16u + q].h_or_y = y[j];
+        }
+        const unsigned long long sb = __ballot(settled);
+        const unsigned done = ((sb & 0xffffull) ? 1u : 0u) | ((sb & 0xffff0000ull) ? 2u : 0u) | ((sb & 0xffff00000000ull) ? 4u : 0u) |
+                              ((sb >> 48) ? 8u : 0u);
+        mask &= ~(unsigned)rfl((int)done);
+        SOLVER_SYNC();
+        if ((mask & 15u) == 0u) return;
+    }
+#endif
     SolverLds L(S.net, S.ws[w]);
     const LaneNet lnet = lane_net(P, lane);
 #pragma unroll 1

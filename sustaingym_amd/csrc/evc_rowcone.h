@@ -1,0 +1,334 @@
+// evc_rowcone.h — the action projection (env.py:178-221) of FOUR environments at once, one per 16-lane DPP row, for the
+// environments whose box-clipped action leaves one or two constraint rows violated (a class cap counts as a row: its own
+// simple row of the matrix).  Same mathematics as wave_cone (evc_solver.h: conic dual, Levenberg-Marquardt Newton on the
+// active rows, full steps, exact KKT test) in the geometry of the quad kernels: lane q of a row owns stations q, q + 16,
+// q + 32, q + 48 of its environment, every sum of an iteration is a per-lane sum over those four slots followed by ONE
+// 16-lane butterfly (row_allreduce_f64: 4 DPP steps instead of the wave ladder's 6 + readlane, and four environments
+// share each instruction).  Used by the fused rollout kernel (evc_rollout.h), where under a greedy policy nearly every
+// environment of a congested network needs such a solve in every period: the wave-per-environment solver behind
+// rollout_solve_rows took the rows of a wavefront one after the other (JPL GMM days under greedy: 6e7 env-steps/s).
+//
+// A row that this file cannot settle — a third row turns up, a multiplier wants to leave the active set, the iteration
+// budget — is reported back and goes through the general path (solve_projection) as before: nothing here decides
+// feasibility on its own, every accepted point has been verified against ALL rows and caps in float64.
+#pragma once
+
+#include "evc_quad.h"
+
+namespace evc {
+
+__device__ __forceinline__ double row_allreduce_max_f64(double v) {
+    v = fmax(v, dpp_f64<0x121, 0xf, false>(v));
+    v = fmax(v, dpp_f64<0x122, 0xf, false>(v));
+    v = fmax(v, dpp_f64<0x124, 0xf, false>(v));
+    v = fmax(v, dpp_f64<0x128, 0xf, false>(v));
+    return v;
+}
+
+// Exact float64 rows of the station-shaped schedule y of MY row's environment (lane q < m evaluates constraint row q):
+// viol = the violated rows (bit c), cap_viol = the classes above their cap, worst = the row furthest above its limit
+// (-1 if none).  All three are uniform over the 16 lanes of a row.
+struct RowExact { unsigned viol; unsigned cap_viol; int worst; };
+__device__ __forceinline__ RowExact quad_exact_rows_worst(int G, const double* class_cap, const LdsNet& net, unsigned q, unsigned m,
+                                                         unsigned row, const int (&st_gid)[kSlots], const double (&y)[kSlots],
+                                                         double tol = Consts::PROJ_TOL) {
+    double re = 0.0, im = 0.0;
+    RowExact out{0u, 0u, -1};
+    for (int g0 = 0; g0 < G; g0 += 4) {
+        double S[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            double part = 0.0;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) part += (st_gid[j] == g0 + u) ? y[j] : 0.0;
+            S[u] = row_allreduce_f64(part);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int g = g0 + u;
+            if (g < G) {
+                if (q < m) { re += net.Mre[g][q] * S[u]; im += net.Mim[g][q] * S[u]; }
+                if (S[u] > class_cap[g] * (1.0 + tol)) out.cap_viol |= 1u << g;
+            }
+        }
+    }
+    double ratio = 0.0;
+    bool viol = false;
+    if (q < m) {
+        const double mg = net.mag[q], lim = mg * (1.0 + tol), m2 = re * re + im * im;
+        viol = m2 > lim * lim;
+        ratio = viol ? m2 / (mg * mg) : 0.0;          // squared ratios order the rows like the ratios do
+    }
+    out.viol = (unsigned)(__ballot(viol) >> (row * 16u)) & 0xffffu;
+    if (__ballot(viol) != 0ull) {
+        const double best = row_allreduce_max_f64(ratio);
+        const unsigned at = (unsigned)(__ballot(viol && ratio == best) >> (row * 16u)) & 0xffffu;
+        out.worst = at ? (int)__builtin_ctz(at) : -1;
+    }
+    return out;
+}
+
+// The conic-dual Newton on R given rows for the rows with `on` (every quantity row-uniform; rows[] and z[] differ between
+// the rows of the wavefront).  Returns, per row, whether it converged (yout = the optimum given THESE active rows; the
+// caller verifies the other rows).  Mirrors wave_cone<R> statement by statement; see there for the algorithm.
+template <int R>
+__device__ __forceinline__ bool quad_cone(const LdsNet& net, unsigned row, bool on, const int (&st_gid)[kSlots],
+                                          const double (&b)[kSlots], const double (&h)[kSlots], const int (&rows)[R],
+                                          double (&z)[2 * R], double (&yout)[kSlots]) {
+    constexpr int D = 2 * R;
+    double cf[D][kSlots], rmag[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int c = rows[r] >= 0 ? rows[r] : 0;
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            cf[2 * r][j] = st_gid[j] >= 0 ? net.Mre[st_gid[j]][c] : 0.0;
+            cf[2 * r + 1][j] = st_gid[j] >= 0 ? net.Mim[st_gid[j]][c] : 0.0;
+        }
+        rmag[r] = net.mag[c];
+    }
+    double mu = 1e-3;
+    bool run = on, ok = false;
+    bool was_free[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) was_free[j] = false;
+    bool have_K = false;
+    double K[D][D];
+    for (int it = 0; it < (R == 1 ? 14 : 24) && __ballot(run) != 0ull; it++) {
+        double y[kSlots];
+        bool fr[kSlots], moved = false;
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            double nu = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; a++) nu += cf[a][j] * z[a];
+            const double v = b[j] - nu;
+            y[j] = st_gid[j] >= 0 ? fmin(fmax(v, 0.0), h[j]) : 0.0;
+            fr[j] = st_gid[j] >= 0 && (v > 0.0) && (v <= h[j]) && (h[j] > 0.0);
+            moved = moved || fr[j] != was_free[j];
+            was_free[j] = fr[j];
+        }
+        double w[D];
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            double part = 0.0;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) part += cf[a][j] * y[j];
+            w[a] = row_allreduce_f64(part);
+        }
+        // K depends on the multipliers only through the set of free stations: summed again when that set changed in any
+        // running row (rows whose set did not change get the same values again)
+        if (!have_K || __ballot(run && moved) != 0ull) {
+#pragma unroll
+            for (int a = 0; a < D; a++)
+#pragma unroll
+                for (int e = a; e < D; e++) {
+                    double part = 0.0;
+#pragma unroll
+                    for (int j = 0; j < kSlots; j++) part += fr[j] ? cf[a][j] * cf[e][j] : 0.0;
+                    K[a][e] = row_allreduce_f64(part);
+                }
+            have_K = true;
+        }
+        if (it == 0) {
+            // the row without a multiplier: alone, the first-order size along its w; beside an active row, tiny
+            const int a0 = D - 2;
+            const double nw = sqrt(w[a0] * w[a0] + w[a0 + 1] * w[a0 + 1]);
+            if (!(nw > rmag[R - 1])) run = false;                       // (not violated after all: the general path decides)
+            const double wh0 = w[a0] / nw, wh1 = w[a0 + 1] / nw;
+            double lam = 1e-6;
+            if (R == 1) {
+                const double curv = wh0 * (K[0][0] * wh0 + K[0][1] * wh1) + wh1 * (K[0][1] * wh0 + K[1][1] * wh1);
+                if (curv > 0.0) lam = fmax((nw - rmag[0]) / curv, 1e-6);
+            }
+            if (run) { z[a0] = lam * wh0; z[a0 + 1] = lam * wh1; }
+            continue;
+        }
+        double zh[D], g[D], rn[R];
+        bool conv = true;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const double inz = 1.0 / sqrt(z[2 * r] * z[2 * r] + z[2 * r + 1] * z[2 * r + 1]);
+            zh[2 * r] = z[2 * r] * inz;
+            zh[2 * r + 1] = z[2 * r + 1] * inz;
+            g[2 * r] = w[2 * r] - rmag[r] * zh[2 * r];
+            g[2 * r + 1] = w[2 * r + 1] - rmag[r] * zh[2 * r + 1];
+            rn[r] = rmag[r] * inz;
+            const double lim = Consts::PROJ_TOL_KKT * rmag[r];
+            conv = conv && g[2 * r] * g[2 * r] + g[2 * r + 1] * g[2 * r + 1] <= lim * lim;
+        }
+        if (run && conv) {
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) yout[j] = y[j];
+            ok = true;
+            run = false;
+        }
+        double B[D][D];
+#pragma unroll
+        for (int a = 0; a < D; a++)
+#pragma unroll
+            for (int e = 0; e < D; e++) B[a][e] = a <= e ? K[a][e] : K[e][a];
+        double tr = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int a = 2 * r;
+            B[a][a] += rn[r] * (1.0 - zh[a] * zh[a]);
+            B[a + 1][a + 1] += rn[r] * (1.0 - zh[a + 1] * zh[a + 1]);
+            B[a][a + 1] -= rn[r] * zh[a] * zh[a + 1];
+            B[a + 1][a] = B[a][a + 1];
+            tr += B[a][a] + B[a + 1][a + 1];
+        }
+        double scale = tr / (double)D;
+        scale = scale < 1e-12 ? 1e-12 : scale;
+#pragma unroll
+        for (int a = 0; a < D; a++) B[a][a] += mu * scale;
+        bool good = true;                          // Gauss elimination without pivoting (SPD + shift)
+        double inv[D];
+#pragma unroll
+        for (int a = 0; a < D; a++) {
+            good = good && B[a][a] > 0.0;
+            inv[a] = 1.0 / B[a][a];
+#pragma unroll
+            for (int e = a + 1; e < D; e++) {
+                const double f = B[e][a] * inv[a];
+#pragma unroll
+                for (int u = a + 1; u < D; u++) B[e][u] -= f * B[a][u];
+                g[e] -= f * g[a];
+            }
+        }
+        double d[D];
+#pragma unroll
+        for (int a = D - 1; a >= 0; a--) {
+            double t = g[a];
+#pragma unroll
+            for (int u = a + 1; u < D; u++) t -= B[a][u] * d[u];
+            d[a] = t * inv[a];
+        }
+        if (!good) run = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const double t0 = z[2 * r] + d[2 * r], t1 = z[2 * r + 1] + d[2 * r + 1];
+            if (!(t0 * z[2 * r] + t1 * z[2 * r + 1] > 0.0)) run = false;     // the row would leave the active set
+        }
+        if (run) {
+#pragma unroll
+            for (int a = 0; a < D; a++) z[a] += d[a];
+        }
+        mu = fmax(mu * 0.25, 1e-12);
+    }
+    return ok;
+}
+
+// Water-filling of class g on (b, h) — quad_waterfill's iteration without its tie snap (the caller snaps once, at the end).
+__device__ __forceinline__ void quad_waterfill_bh(bool on, int g, const int (&st_gid)[kSlots], const double (&b)[kSlots],
+                                                  const double (&h)[kSlots], double cap, double (&y)[kSlots]) {
+    bool in_g[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) in_g[j] = st_gid[j] == g;
+    double nu = 0.0, lo = 0.0, hi = 64.0;
+    bool run = on;
+    for (int it = 0; it < 80 && __ballot(run) != 0ull; it++) {
+        double part = 0.0;
+        unsigned nfree = 0u;
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            const double v = b[j] - nu;
+            part += in_g[j] ? fmin(fmax(v, 0.0), h[j]) : 0.0;
+            nfree += (in_g[j] && v > 0.0 && v <= h[j] && h[j] > 0.0) ? 1u : 0u;
+        }
+        const double f = row_allreduce_f64(part) - cap;
+        const unsigned kfree = row_allreduce_u32(nfree);
+        double bp = 0.0;
+        if (__builtin_expect(__ballot(run && kfree == 0u && f > 0.0) != 0ull, 0)) {
+            double nextbp = 1e300;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) nextbp = fmin(nextbp, (in_g[j] && b[j] - nu > h[j]) ? b[j] - h[j] : 1e300);
+            bp = row_allreduce_min_f64(nextbp);
+        }
+        if (run) {
+            if (fabs(f) <= 1e-13 * cap) {
+                run = false;
+            } else {
+                if (f > 0.0) lo = nu; else hi = nu;
+                double nxt = (kfree > 0u) ? nu + f / (double)kfree : (f > 0.0 ? bp : 0.5 * (lo + hi));
+                if (!(nxt > lo && nxt < hi)) nxt = 0.5 * (lo + hi);
+                nu = nxt;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kSlots; j++)
+        if (on && in_g[j]) y[j] = fmin(fmax(b[j] - nu, 0.0), h[j]);
+}
+
+// solve_projection's relaxation sequence for the rows with `on`, in row geometry: exact test of the box clip -> class caps
+// by water-filling (exact if every row holds afterwards) -> one cone row -> two.  Returns (row-uniform) whether the row is
+// settled; y then holds the projection (values the solver moved are tie-snapped like solve_projection's).
+__device__ __forceinline__ bool quad_project(int G, const double* class_cap, unsigned long long* tie_counters, const LdsNet& net,
+                                             unsigned q, unsigned m, unsigned row, bool on, const int (&st_gid)[kSlots],
+                                             const bool (&is_cc)[kSlots], const double (&b)[kSlots], const double (&h)[kSlots],
+                                             double (&y)[kSlots]) {
+    double y0[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) { y0[j] = fmin(b[j], h[j]); y[j] = y0[j]; }
+    const RowExact e0 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y0);
+    bool settled = on && e0.viol == 0u && e0.cap_viol == 0u;
+    bool open = on && !settled;
+    // caps first, also beside violated multi-class rows (relaxation argument, evc_solver.h)
+    const bool fill = open && e0.cap_viol != 0u;
+    if (__ballot(fill) != 0ull) {
+        double yw[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) yw[j] = y0[j];
+        for (int g = 0; g < G; g++) {
+            const bool do_g = fill && ((e0.cap_viol >> g) & 1u);
+            if (__ballot(do_g) != 0ull) quad_waterfill_bh(do_g, g, st_gid, b, h, class_cap[g], yw);
+        }
+        const RowExact ew = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, yw);
+        const bool okw = fill && ew.viol == 0u && ew.cap_viol == 0u;
+        if (okw) {
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) y[j] = yw[j];
+        }
+        settled = settled || okw;
+        open = open && !okw;
+    }
+    if (__ballot(open) != 0ull) {
+        const int r1[1] = {e0.worst};
+        double z1[2] = {0.0, 0.0}, y1[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) y1[j] = 0.0;
+        const bool c1 = quad_cone<1>(net, row, open && e0.worst >= 0, st_gid, b, h, r1, z1, y1);
+        const RowExact e1 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y1);
+        const bool ok1 = c1 && e1.viol == 0u && e1.cap_viol == 0u;
+        if (ok1) {
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) y[j] = y1[j];
+        }
+        settled = settled || ok1;
+        const bool go2 = c1 && !ok1 && e1.viol != 0u && e1.worst != e0.worst && e1.worst >= 0;
+        if (__ballot(go2) != 0ull) {
+            const int r2[2] = {e0.worst, e1.worst};
+            double z2[4] = {z1[0], z1[1], 0.0, 0.0}, y2[kSlots];
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) y2[j] = 0.0;
+            const bool c2 = quad_cone<2>(net, row, go2, st_gid, b, h, r2, z2, y2);
+            const RowExact e2 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y2);
+            const bool ok2 = c2 && e2.viol == 0u && e2.cap_viol == 0u;
+            if (ok2) {
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) y[j] = y2[j];
+            }
+            settled = settled || ok2;
+        }
+    }
+    // Tie snap: values the solver moved go to the 2^-16 A grid, exactly as solve_projection does it
+    if (__ballot(settled) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < kSlots; j++)
+            if (settled && st_gid[j] >= 0 && y[j] != y0[j]) y[j] = tie_snap_counted(y[j], h[j], is_cc[j], tie_counters);
+    }
+    return settled;
+}
+
+}  // namespace evc

@@ -405,6 +405,13 @@ __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, 
         rmag[r] = net.mag[rows[r]];
     }
     double mu = 1e-3;
+    // K_ab = sum over the FREE stations of c_a c_b depends on the multipliers only through which stations are free: it is
+    // summed again only when that set changed since the last iteration (same values either way; a D = 6 iteration is 6 wave
+    // sums instead of 27 once the clamp pattern has settled — a lone wavefront pays ~140 cycles per float64 wave sum,
+    // tools/probes/prim_probe.hip)
+    unsigned long long free_set = 0ull;
+    bool have_K = false;
+    double K[D][D];
     for (int it = 0; it < (R == 1 ? 14 : 24); it++) {
         double nu = 0.0;
 #pragma unroll
@@ -412,12 +419,17 @@ __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, 
         const double v = b - nu;
         const double y = gid >= 0 ? fmin(fmax(v, 0.0), h) : 0.0;
         const bool fr = gid >= 0 && (v > 0.0) && (v <= h) && (h > 0.0);
-        double w[D], K[D][D];
+        double w[D];
 #pragma unroll
-        for (int a = 0; a < D; a++) {
-            w[a] = wave_sum_f64(cf[a] * y);
+        for (int a = 0; a < D; a++) w[a] = wave_sum_f64(cf[a] * y);
+        const unsigned long long now_free = __ballot(fr);
+        if (!have_K || now_free != free_set) {
 #pragma unroll
-            for (int e = a; e < D; e++) K[a][e] = wave_sum_f64(fr ? cf[a] * cf[e] : 0.0);
+            for (int a = 0; a < D; a++)
+#pragma unroll
+                for (int e = a; e < D; e++) K[a][e] = wave_sum_f64(fr ? cf[a] * cf[e] : 0.0);
+            free_set = now_free;
+            have_K = true;
         }
         if (it == 0) {
             // the row without a multiplier: alone, the first-order size along its w; beside an active row, tiny
