@@ -546,11 +546,58 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
             for (int g = 0; g < G; g++)
                 if ((e0.cap_viol >> g) & 1u)
                     yw = waterfill_class(lnet.gid == g, ln.b, ln.h, P.class_cap[g], yw);
-            unsigned cv2;
-            if (exact_rows(P, L.net, lnet, lane, yw, cv2) == 0ull) {
+            const ExactRows ew = exact_rows_worst(P, L.net, lnet, lane, yw);
+            if (ew.viol == 0ull) {
                 ln.y = yw;
                 settled = true;
             }
+#ifndef EVC_ABL_NO_WAVE_CONE
+            else if (__popc(e0.cap_viol) <= 2 && ew.worst >= 0) {
+                // (b2) Caps filled, a row still violated (Caltech's congested middays: a feeder row beside the pod caps — one
+                // such environment per step, and its solve is what the launch waits for).  The caps' own rows and the worst
+                // remaining row, together and at once: the caps' multipliers are known from the filling (a class shifted by
+                // nu_g has z_c = nu_g cf / |cf|^2 on its simple row c, cf = that row's coefficient of the class), the new row
+                // starts as in wave_cone.  One in-register Newton on 2 - 3 rows instead of the chain 1 -> 2 -> 3 below.
+                int rows_b[3] = {-1, -1, -1};
+                double zb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                int nc = 0;
+                bool usable = true;
+                for (int g = 0; g < G; g++) {
+                    if (!((e0.cap_viol >> g) & 1u)) continue;
+                    const unsigned long long rb = __ballot(lane < m && ((P.simple_rows >> lane) & 1u) &&
+                                                           (L.net.Mre[g][lane] != 0.0 || L.net.Mim[g][lane] != 0.0));
+                    const unsigned long long fb = __ballot(lnet.gid == g && yw > 0.0 && yw < ln.h && yw < ln.b);   // strictly inside: y = b - nu
+                    if (rb == 0ull || fb == 0ull) { usable = false; break; }
+                    const int c = __builtin_ctzll(rb);
+                    const double nu = readlane_f64(ln.b - yw, __builtin_ctzll(fb));
+                    const double cre = L.net.Mre[g][c], cim = L.net.Mim[g][c];
+                    const double sc = nu / (cre * cre + cim * cim);
+                    rows_b[nc] = c;
+                    zb[2 * nc] = sc * cre;
+                    zb[2 * nc + 1] = sc * cim;
+                    nc++;
+                }
+                usable = usable && ew.worst != rows_b[0] && ew.worst != rows_b[1];
+                double yb = 0.0;
+                bool got = false;
+                if (usable && nc == 1) {
+                    const int r2[2] = {rows_b[0], ew.worst};
+                    double z2[4] = {zb[0], zb[1], 0.0, 0.0};
+                    got = wave_cone<2>(L.net, lnet.gid, ln.b, ln.h, r2, z2, yb);
+                } else if (usable && nc == 2) {
+                    const int r3[3] = {rows_b[0], rows_b[1], ew.worst};
+                    double z3[6] = {zb[0], zb[1], zb[2], zb[3], 0.0, 0.0};
+                    got = wave_cone<3>(L.net, lnet.gid, ln.b, ln.h, r3, z3, yb);
+                }
+                if (got) {
+                    const ExactRows eb = exact_rows_worst(P, L.net, lnet, lane, yb);
+                    if (eb.viol == 0ull && eb.cap_viol == 0u) {
+                        ln.y = yb;
+                        settled = true;
+                    }
+                }
+            }
+#endif
         }
 #ifndef EVC_ABL_NO_WAVE_CONE
         if (!settled) {
