@@ -628,6 +628,13 @@ def secondary_closed_loop(dev_index, battery) -> dict:
         rec['pipelined_per_half_policy']['pipelined_steps'] = int(after[0] - before[0])
         rec['pipelined_per_half_policy']['steps_ordered_behind_the_engine_stream'] = int(after[1] - before[1])
         out['policy_' + kind] = rec
+    # what the policy costs by itself: its kernel over the whole batch, back to back on one stream (14 MB of ring in, the demand
+    # columns of the 38 MB observation — every 128-byte line they touch — and 14 MB of actions out, per step)
+    for kind in ('min_u', 'greedy'):
+        def only_policy():
+            policy(kind, demands, acts)
+            state['i'] += 1
+        out['policy_' + kind]['policy_kernel_alone'] = timed(only_policy)
     eng.set_pipeline(1)
     out['open_loop_single_launch'] = timed(lambda: w.step(w.ptrs[0]))
     eng.set_pipeline(2)

@@ -6,6 +6,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <climits>
 #include <cstdarg>
@@ -127,6 +128,7 @@ struct evc_engine {
     hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr}, phase_ev = nullptr;
     bool halves_pending = false, side_warmed = false, last_split = false, side_ready = false;
     unsigned train_len = 0, prev_train_len = 0;   // pipelined steps since the last join, and in the train before it
+    std::chrono::steady_clock::time_point last_split_issue{};   // host time of the last pipelined step's issue
     unsigned long long split_steps = 0;   // steps that ran as two half launches (evc_pipelined_steps) ...
     unsigned long long fork_steps = 0;    // ... and how many of them had to be ordered behind pending work of the engine's stream
     // fused rollout: which register budget of the projecting kernels is faster on the caller's workload (launch_rollout)
@@ -509,11 +511,19 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         // from idle streams — after a join, or after the caller drained the device (torch.cuda.synchronize: what a timed
         // window begins with) — would start both halves together.  So the first step of such a train runs half A as TWO
         // quarter launches and lets half B wait for the first quarter: B begins when half of A's work is done, whatever the
-        // workload, at the price of one more prologue (~3 us, once per train).  EVC_PIPE_PHASE=0 turns it off (measurements).
-        static const bool phase_on = !(getenv("EVC_PIPE_PHASE") && atoi(getenv("EVC_PIPE_PHASE")) == 0);
-        bool cold = !e->halves_pending;
-        if (!cold && phase_on && !e->timing)
-            cold = hipStreamQuery(e->side[0]) == hipSuccess && hipStreamQuery(e->side[1]) == hipSuccess;   // drained behind our back
+        // workload, at the price of one more prologue (~3 us, once per train).  Measured on the driver's window (20 steps after
+        // 5 warm-up steps and a device synchronisation, tools/ab_window.sh, 4 interleaved pairs): 25.6 / 25.6 / 27.3 / 25.5 us
+        // per step with it, 26.3 / 25.1 / 24.7 / 25.9 without — what the short window pays is not the lock-step start (the
+        // trains drift apart within three or four steps) but the drained GPU's first launches and the final drain; steady state
+        // 22.99 either way.  No gain: OFF by default, EVC_PIPE_PHASE=1 turns it on.
+        static const bool phase_on = getenv("EVC_PIPE_PHASE") && atoi(getenv("EVC_PIPE_PHASE")) != 0;
+        // "drained behind our back" is told by the host clock, not by querying the streams (two runtime calls per step, and a
+        // host that is only just ahead of the GPU would find them idle again and again): a gap of more than 200 us since the
+        // last pipelined step was issued is at least eight step times — the trains have run dry.
+        const auto now = std::chrono::steady_clock::now();
+        const double gap_us = std::chrono::duration<double, std::micro>(now - e->last_split_issue).count();
+        e->last_split_issue = now;
+        const bool cold = !e->halves_pending || (phase_on && gap_us > 200.0);
         const bool phased = cold && phase_on && !e->timing && mid >= 64;
         if (cold) { e->prev_train_len = e->train_len; e->train_len = 0; }
         e->train_len++;

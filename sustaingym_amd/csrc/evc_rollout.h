@@ -85,7 +85,7 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
             h[j] = valid ? S.img[w][row][st].h_or_y : 0.0;
             b[j] = !valid ? 0.0 : (mask & 16u) ? (double)S.act_img[w][row][st] * Consts::ACTION_SCALE_FACTOR : Consts::ACTION_SCALE_FACTOR;
         }
-        const bool settled = quad_project(S.rare.G, S.rare.class_cap, P.tie_counters, S.net, q, (unsigned)P.m, row, on, st_gid, is_cc, b, h, y);
+        const bool settled = quad_project(S.rare.G, S.rare.class_cap, S.rare.simple_rows, P.tie_counters, S.net, q, (unsigned)P.m, row, on, st_gid, is_cc, b, h, y);
         if (settled) {
 #pragma unroll
             for (int j = 0; j < kSlots; j++)
@@ -97,6 +97,9 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
         mask &= ~(unsigned)rfl((int)done);
         SOLVER_SYNC();
         if ((mask & 15u) == 0u) return;
+#if defined(EVC_RABL) && EVC_RABL == 5   /* ablation (WRONG results): rows the row-form solver did not settle are left as they are */
+        return;
+#endif
     }
 #endif
     SolverLds L(S.net, S.ws[w]);
@@ -376,7 +379,11 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
             }
             const bool undecided = live && row_any(maybe, row);
             pilots_screened = !row_any(maybe_p, row);
+#if defined(EVC_RABL) && EVC_RABL == 1   /* ablation builds only (WRONG results): the period without the rare projection branch */
+            if (false) {
+#else
             if (__builtin_expect(__ballot(undecided) != 0ull, 0)) {
+#endif
                 int st_gid[kSlots];
 #pragma unroll
                 for (int c = 0; c < kSlots; c++) st_gid[c] = valid[c] ? (int)(st_info[st[c]] & 0x7fu) : -1;
@@ -411,7 +418,12 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                     const bool hard = quad_exact_rows(S.rare.G, S.rare.class_cap, net, q, m, st_gid, y, undecided, cap_viol);
                     anyviol = row_any(hard, row);
                 }
+#if defined(EVC_RABL) && EVC_RABL == 2   /* ablation (WRONG results): exact rows only */
+                const bool fill = false;
+                anyviol = false;
+#else
                 const bool fill = undecided && cap_viol != 0u;
+#endif
                 if (__builtin_expect(__ballot(fill) != 0ull, 0)) {
                     bool slot_cc[kSlots];
 #pragma unroll
@@ -420,12 +432,20 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
                         if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, S.rare.class_cap[g], y, slot_cc, nullptr);
                     }
+#if defined(EVC_RABL) && EVC_RABL == 3   /* ablation (WRONG results): exact rows + filling, no second evaluation, no solve */
+                    anyviol = false;
+                    if (false) {
+#else
                     if (!shortcut) {
+#endif
                         unsigned cv2;
                         const bool still = row_any(quad_exact_rows(S.rare.G, S.rare.class_cap, net, q, m, st_gid, y, fill, cv2, S.rare.snap_tol), row);
                         anyviol = anyviol && !(fill && !still);
                     }
                 }
+#if defined(EVC_RABL) && EVC_RABL == 4   /* ablation (WRONG results): everything but the solve */
+                anyviol = false;
+#endif
                 const bool solve_me = undecided && anyviol;       // cone rows bind (or unsettled): iterative solver
                 const unsigned long long solve_mask = __ballot(solve_me);
                 if (__builtin_expect(solve_mask != 0ull, 0)) {

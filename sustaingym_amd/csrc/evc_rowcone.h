@@ -262,9 +262,10 @@ __device__ __forceinline__ void quad_waterfill_bh(bool on, int g, const int (&st
 }
 
 // solve_projection's relaxation sequence for the rows with `on`, in row geometry: exact test of the box clip -> class caps
-// by water-filling (exact if every row holds afterwards) -> one cone row -> two.  Returns (row-uniform) whether the row is
+// by water-filling (exact if every row holds afterwards) -> one violated cap's row + the worst remaining row at once, or the
+// chain one cone row -> two.  Returns (row-uniform) whether the row is
 // settled; y then holds the projection (values the solver moved are tie-snapped like solve_projection's).
-__device__ __forceinline__ bool quad_project(int G, const double* class_cap, unsigned long long* tie_counters, const LdsNet& net,
+__device__ __forceinline__ bool quad_project(int G, const double* class_cap, unsigned simple_rows, unsigned long long* tie_counters, const LdsNet& net,
                                              unsigned q, unsigned m, unsigned row, bool on, const int (&st_gid)[kSlots],
                                              const bool (&is_cc)[kSlots], const double (&b)[kSlots], const double (&h)[kSlots],
                                              double (&y)[kSlots]) {
@@ -274,6 +275,9 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
     const RowExact e0 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y0);
     bool settled = on && e0.viol == 0u && e0.cap_viol == 0u;
     bool open = on && !settled;
+    bool d2 = false;                               // a pair of rows to solve together, from the filling or from the chain
+    int pair[2] = {-1, -1};
+    double zp[2] = {0.0, 0.0};
     // caps first, also beside violated multi-class rows (relaxation argument, evc_solver.h)
     const bool fill = open && e0.cap_viol != 0u;
     if (__ballot(fill) != 0ull) {
@@ -292,7 +296,46 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
         }
         settled = settled || okw;
         open = open && !okw;
+        // Caps filled, a row still violated: the caps' own rows and the worst remaining row together, the caps' multipliers
+        // taken from the filling (a class shifted by nu has z_c = nu cf / |cf|^2 on its simple row c) — solve_projection's (b2).
+        const bool direct = fill && !okw && __popc(e0.cap_viol) <= 2 && ew.worst >= 0;
+        if (__ballot(direct) != 0ull) {
+            int crow[2] = {-1, -1};
+            double zc[4] = {0.0, 0.0, 0.0, 0.0};
+            int nc = 0;
+            bool usable = direct;
+            for (int g = 0; g < G; g++) {
+                const bool mine = direct && ((e0.cap_viol >> g) & 1u);
+                if (__ballot(mine) == 0ull) continue;
+                const bool is_row = q < m && ((simple_rows >> q) & 1u) && (net.Mre[g][q] != 0.0 || net.Mim[g][q] != 0.0);
+                const unsigned rb = (unsigned)(__ballot(is_row) >> (row * 16u)) & 0xffffu;
+                double cand = -1.0;
+#pragma unroll
+                for (int j = 0; j < kSlots; j++)
+                    if (st_gid[j] == g && yw[j] > 0.0 && yw[j] < h[j] && yw[j] < b[j]) cand = fmax(cand, b[j] - yw[j]);
+                const double nu = row_allreduce_max_f64(cand);
+                if (mine) {
+                    if (rb == 0u || !(nu > 0.0) || nc >= 2) {
+                        usable = false;
+                    } else {
+                        const int c = (int)__builtin_ctz(rb);
+                        const double cre = net.Mre[g][c], cim = net.Mim[g][c];
+                        const double sc = nu / (cre * cre + cim * cim);
+                        if (nc == 0) { crow[0] = c; zc[0] = sc * cre; zc[1] = sc * cim; }
+                        else { crow[1] = c; zc[2] = sc * cre; zc[3] = sc * cim; }
+                        nc++;
+                    }
+                }
+            }
+            usable = usable && nc >= 1 && ew.worst != crow[0] && ew.worst != crow[1];
+            // (three rows — both pods beside a feeder row — in this geometry cost every copy of the period's body its registers:
+            // scratch 444 -> 1584 B, Caltech GMM greedy 57 -> 78 us per period, measured; those rows go to the general path)
+            d2 = usable && nc == 1;
+            if (d2) { pair[0] = crow[0]; pair[1] = ew.worst; zp[0] = zc[0]; zp[1] = zc[1]; }
+            open = open && !d2;                    // (a direct attempt that fails goes to the general path, not through the chain)
+        }
     }
+    bool go2 = false;
     if (__ballot(open) != 0ull) {
         const int r1[1] = {e0.worst};
         double z1[2] = {0.0, 0.0}, y1[kSlots];
@@ -306,21 +349,24 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
             for (int j = 0; j < kSlots; j++) y[j] = y1[j];
         }
         settled = settled || ok1;
-        const bool go2 = c1 && !ok1 && e1.viol != 0u && e1.worst != e0.worst && e1.worst >= 0;
-        if (__ballot(go2) != 0ull) {
-            const int r2[2] = {e0.worst, e1.worst};
-            double z2[4] = {z1[0], z1[1], 0.0, 0.0}, y2[kSlots];
+        go2 = c1 && !ok1 && e1.viol != 0u && e1.worst != e0.worst && e1.worst >= 0;
+        if (go2) { pair[0] = e0.worst; pair[1] = e1.worst; zp[0] = z1[0]; zp[1] = z1[1]; }
+    }
+    // ONE two-row solve for both sources of a pair (one inlined copy of quad_cone<2>: registers)
+    const bool want2 = d2 || go2;
+    if (__ballot(want2) != 0ull) {
+        const int r2[2] = {pair[0], pair[1]};
+        double z2[4] = {zp[0], zp[1], 0.0, 0.0}, y2[kSlots];
 #pragma unroll
-            for (int j = 0; j < kSlots; j++) y2[j] = 0.0;
-            const bool c2 = quad_cone<2>(net, row, go2, st_gid, b, h, r2, z2, y2);
-            const RowExact e2 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y2);
-            const bool ok2 = c2 && e2.viol == 0u && e2.cap_viol == 0u;
-            if (ok2) {
+        for (int j = 0; j < kSlots; j++) y2[j] = 0.0;
+        const bool c2 = quad_cone<2>(net, row, want2, st_gid, b, h, r2, z2, y2);
+        const RowExact e2 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y2);
+        const bool ok2 = c2 && e2.viol == 0u && e2.cap_viol == 0u;
+        if (ok2) {
 #pragma unroll
-                for (int j = 0; j < kSlots; j++) y[j] = y2[j];
-            }
-            settled = settled || ok2;
+            for (int j = 0; j < kSlots; j++) y[j] = y2[j];
         }
+        settled = settled || ok2;
     }
     // Tie snap: values the solver moved go to the 2^-16 A grid, exactly as solve_projection does it
     if (__ballot(settled) != 0ull) {

@@ -92,7 +92,7 @@ def test_product_build_defines_no_measurement_switch():
             src = open(os.path.join(root, 'csrc', f)).read()
             switches |= set(re.findall(r'#\s*if(?:def|ndef)?\s+(?:defined\()?(EVC_ABL_\w+)', src))
     docs = open(os.path.join(repo, 'DESIGN.md')).read() + open(os.path.join(repo, 'tools', 'README.md')).read() \
-        + open(os.path.join(repo, 'tools', 'scratch', 'abl_fill.sh')).read()
+        + open(os.path.join(repo, 'tools', 'abl_fill.sh')).read()
     assert switches, 'no ablation switch found: the pattern of this test is stale'
     missing = sorted(s for s in switches if s not in docs)
     assert not missing, f'ablation switches without a word in DESIGN.md / tools/README.md: {missing}'

@@ -4,6 +4,6 @@
 #   pass0 / pass1: the Newton loop cut off after 0 / 1 passes (-DEVC_ABL_FILL_PASSES)   norev: no second evaluation of the rows
 #   nofill: exact rows only (-DEVC_ABL_NO_FILL)
 for v in base pass1 pass0 norev nofill base; do
-  if [ $v = base ]; then echo "base $(python tools/scratch/gmm_blocks.py caltech 2>/dev/null)"
-  else echo "$v $(SUSTAINGYM_AMD_LIB=$PWD/sustaingym_amd/variants/lib_$v.so python tools/scratch/gmm_blocks.py caltech 2>/dev/null)"; fi
+  if [ $v = base ]; then echo "base $(python tools/gmm_days.py caltech 2>/dev/null)"
+  else echo "$v $(SUSTAINGYM_AMD_LIB=$PWD/sustaingym_amd/variants/lib_$v.so python tools/gmm_days.py caltech 2>/dev/null)"; fi
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the streaming kernel (two passes), per env-step.  Usage: tools/scratch/pmc_sq.sh [layout]
+# SQ counters of the streaming kernel (two passes), per env-step.  Usage: tools/pmc_sq.sh [layout]
 LAY=${1:-compact}
 REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_sq_$LAY; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 EVC_LAYOUT=$LAY rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/a -o bench -- python $REPO/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-secondary --pipeline 1 --kernel-timing-steps 1 > /dev/null 2> $OUT/a.err

@@ -3,7 +3,7 @@
 set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out/fetch_calib; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o calib -- $REPO/tools/scratch/fetch_calib > $OUT/expected.txt 2> $OUT/err.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o calib -- $REPO/tools/probes/fetch_calib > $OUT/expected.txt 2> $OUT/err.txt
 cd $REPO
 python - <<'PY'
 import pandas as pd, glob
