@@ -818,12 +818,12 @@ def secondary_multiagent(dev_index, battery) -> dict:
     return rec
 
 
-def secondary_battery(dev_index) -> dict:
+def secondary_battery(dev_index, N=16384) -> dict:
     """BASELINE configs[3] (one GPU's share, 16 384 of 131 072 environments): the synthetic battery-dispatch
     step of include/battery_dispatch.h (no reference implementation exists)."""
     import torch
     from sustaingym_amd.battery import BatteryDispatchVectorEnv, synthetic_market_traces
-    N, k = 16384, 36
+    k = 36
     env = BatteryDispatchVectorEnv(N, k, bank_slots=1024, device=dev_index, output='torch')
     env.upload_traces(synthetic_market_traces(1024, k, seed=3))
     env.reset(np.arange(N) % 1024)
@@ -867,6 +867,44 @@ def secondary_battery(dev_index) -> dict:
                          'note': 'launch-latency bound at this size (940 B x 16 384 = 15 MB per launch): compare empty_launch_ms'},
             'host_issue_ms_per_step': round(issue, 5),
             'empty_launch_ms': round(empty, 5), 'over_empty_launch': round(gpu / empty, 2)}
+
+
+def secondary_battery_rollout(dev_index, N=16384, T=EPISODE) -> dict:
+    """the battery step as T periods per launch (bat_rollout): bids from a device-resident ring, every step's
+    observation and reward written to a trajectory buffer (what a learner's rollout buffer holds) — the traffic of 288 calls of
+    bat_step without 288 launch boundaries — and the form without the trajectory (last outputs only)."""
+    import torch
+    from sustaingym_amd.battery import BatteryDispatchVectorEnv, synthetic_market_traces
+    k, R = 36, 8
+    env = BatteryDispatchVectorEnv(N, k, bank_slots=1024, device=dev_index, output='torch')
+    env.upload_traces(synthetic_market_traces(1024, k, seed=3))
+    dev = torch.device('cuda', dev_index)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    ring = (torch.rand((R, N, 2 * k), device=dev, generator=g) * 90.0).contiguous()
+    traj = (torch.empty((T, N, 4 * k + 6), dtype=torch.float32, device=dev), torch.empty((T, N), dtype=torch.float64, device=dev))
+    slots = np.arange(N) % 1024
+    out = {}
+    for name, trajectory in (('with_trajectory', True), ('last_outputs_only', False)):
+        ms = []
+        for rep in range(6):
+            env.reset(slots)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            env.rollout(ring, T, trajectory=trajectory, out=traj if trajectory else None)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms.append(e0.elapsed_time(e1))
+        best = float(np.median(ms[1:]))
+        alg = 2 * k * 4 + 12 + ((4 * k + 6) * 4 + 8 if trajectory else 0)       # bids + traces in; observation + reward out
+        out[name] = {'episode_ms': round(best, 4), 'us_per_step': round(best / T * 1e3, 3), 'env_steps_per_s': round(N * T / best * 1e3, 1),
+                     'roofline': {'bound': 'hbm', 'kernel': 'bat_rollout_kernel', 'algorithmic_bytes_per_env_step': alg,
+                                  'achieved': round(alg * N * T / (best * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': round(alg * N * T / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    env.close()
+    out['workload'] = f'{N} battery-dispatch envs x {T} steps in one launch, bids from a ring of {R} batches, k={k}; trajectory = [{T}, {N}, {4 * k + 6}] float32 + rewards'
+    return out
 
 
 def main():
@@ -1013,6 +1051,7 @@ def main():
                          ('rccl_world1', secondary_rccl_world1),
                          ('multiagent_8192x54', lambda: secondary_multiagent(local_rank, args.battery)),
                          ('battery_16384', lambda: secondary_battery(local_rank)),
+                         ('battery_rollout_16384', lambda: secondary_battery_rollout(local_rank)),
                          ('tie_snap_reach', lambda: secondary_tie_snap(local_rank, args.battery))):
             try:
                 secondary[name] = fn()

@@ -64,6 +64,15 @@ int bat_reset(bat_engine* e, const int32_t* slots, float* obs_dev);
 /* bids: device float32 [N][2k] = (a^c[k], a^d[k]); reward float64 [N]; terminated uint8 [N]. */
 int bat_step(bat_engine* e, const float* bids_dev, float* obs_dev, double* reward_dev,
              uint8_t* terminated_dev);
+/* T steps in ONE launch (round 4; the f2 pattern of the EV engine): equivalent to `steps` calls of bat_step with the bids of
+ * step i = bids_ring_dev[i % ring_len] (device float32 [ring_len][N][2k]); an environment's t, e and running return stay in
+ * registers between its steps.  obs / reward / terminated receive the LAST step's outputs.  With obs_traj_dev / reward_traj_dev
+ * (device float32 [steps][N][4k+6] / float64 [steps][N]; either may be NULL) EVERY step's observation and reward are also written
+ * — the rollout buffer a learner reads: then the launch moves what `steps` calls move (2k bids in, 4k+6 floats out per
+ * environment-step) without `steps` launch boundaries.  Steps after an episode's end are no-ops (reward 0 in reward_traj, the
+ * observation rows of those steps are not written). */
+int bat_rollout(bat_engine* e, const float* bids_ring_dev, int32_t ring_len, int32_t steps, float* obs_dev, double* reward_dev,
+                uint8_t* terminated_dev, float* obs_traj_dev, double* reward_traj_dev);
 /* the same with host buffers (staged through engine-owned device buffers) */
 int bat_reset_host(bat_engine* e, const int32_t* slots, float* obs_host);
 int bat_step_host(bat_engine* e, const float* bids_host, float* obs_host, double* reward_host,

@@ -119,6 +119,26 @@ class BatteryDispatchVectorEnv:
                                            self._term.ctypes.data), 'bat_step_host')
         return self._obs.copy(), self._rew.copy(), self._term.astype(bool)
 
+    def rollout(self, bids_ring, steps: int, trajectory: bool = False, out=None):
+        """``steps`` steps in ONE launch (``bat_rollout``): step i uses ``bids_ring[i % R]`` (CUDA float32 ``[R, N, 2k]``).
+        Returns ``(obs, reward, terminated)`` of the last step (the persistent buffers of ``step``) and, with
+        ``trajectory=True``, also ``(obs_traj [steps, N, 4k+6] float32, reward_traj [steps, N] float64)`` — every step's
+        observation and reward, what a learner's rollout buffer holds (pass ``out=(obs_traj, reward_traj)`` to reuse buffers)."""
+        import torch
+        assert self.output == 'torch' and bids_ring.is_cuda and bids_ring.dtype == torch.float32 and bids_ring.is_contiguous()
+        assert bids_ring.dim() == 3 and tuple(bids_ring.shape[1:]) == (self.N, 2 * self.k)
+        obs, rew, term = self._device_buffers()
+        traj = None
+        if trajectory:
+            traj = out if out is not None else (torch.empty((steps, self.N, self.F), dtype=torch.float32, device=obs.device),
+                                                torch.empty((steps, self.N), dtype=torch.float64, device=obs.device))
+            assert tuple(traj[0].shape) == (steps, self.N, self.F) and tuple(traj[1].shape) == (steps, self.N)
+        self._check(self.lib.bat_rollout(self.handle, C.c_void_p(bids_ring.data_ptr()), int(bids_ring.shape[0]), int(steps),
+                                         C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(term.data_ptr()),
+                                         C.c_void_p(traj[0].data_ptr()) if traj else None,
+                                         C.c_void_p(traj[1].data_ptr()) if traj else None), 'bat_rollout')
+        return (obs, rew, term) + ((traj,) if traj else ())
+
     def make_stepper(self):
         """Lean per-step callable for throughput loops (the counterpart of ``StepEngine.make_stepper``): binds the current
         torch stream and the output buffers once and returns ``(step(ptr: int) -> None, (obs, reward, terminated))`` where

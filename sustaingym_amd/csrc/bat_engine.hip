@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -172,6 +173,140 @@ __global__ __launch_bounds__(256) void bat_step_kernel(BatParams P, const float*
     }
 }
 
+// T steps per launch (bat_rollout): the step above in a loop, state in registers.  Same geometry (a 16-lane row per
+// environment, the observation row as 8-byte pairs).  The bids of step i + 1 are requested before step i is computed and the
+// trace values of step i + 1 are known addresses (t advances by one), so a row always has one step's loads in flight behind
+// the stores of the step before: with a trajectory buffer the launch is a stream of 2k-float reads and (4k+6)-float writes
+// per environment-step and nothing else.
+// LPE = lanes per environment: 16 (the step kernel's geometry: 4 096 wavefronts for 16 384 environments, 4 per SIMD) or 64 (a
+// wavefront per environment: four times as many loops in flight — measured slower, see bat_rollout).
+template <int LPE>
+__global__ __launch_bounds__(256) void bat_rollout_kernel(BatParams P, const float* __restrict__ ring, int ring_len, int steps,
+                                                          float* __restrict__ obs, double* __restrict__ reward,
+                                                          unsigned char* __restrict__ terminated, float* __restrict__ obs_traj,
+                                                          double* __restrict__ reward_traj) {
+    const int q = threadIdx.x & (LPE - 1);
+    const int env = (blockIdx.x * 256 + threadIdx.x) / LPE;
+    if (env >= P.N) return;
+    const int k = P.k, F = P.F;
+    constexpr int kPairPasses = ((4 * BAT_MAX_FORECAST + 6) / 2 + LPE - 1) / LPE;
+    int t = P.t[env];
+    const int slot = P.slot[env];
+    double e = P.energy[env];
+    double ret = P.ret[env];
+    const double term_price = P.terminal_price[slot];
+    const float* price = P.price + (size_t)slot * BAT_TRACE_LEN;
+    const float* load = P.load + (size_t)slot * BAT_TRACE_LEN;
+    const float* moer = P.moer + (size_t)slot * BAT_TRACE_LEN;
+    const float* lfc0 = P.load_fc + (size_t)slot * (BAT_TRACE_LEN + k);
+    const float* mfc0 = P.moer_fc + (size_t)slot * (BAT_TRACE_LEN + k);
+    const size_t row_bids = (size_t)2 * k, batch_bids = (size_t)P.N * row_bids;
+    auto load_bids = [&](int i, float2 (&dst)[kPairPasses], float& bc, float& bd) {
+        const float* a = ring + (size_t)(i % ring_len) * batch_bids + (size_t)env * row_bids;
+        bc = a[0];
+        bd = a[k];
+#pragma unroll
+        for (int j = 0; j < kPairPasses; j++) {
+            const int pr = q + LPE * j;
+            dst[j] = (pr >= 1 && pr <= k) ? *reinterpret_cast<const float2*>(a + 2 * (pr - 1)) : make_float2(0.0f, 0.0f);
+        }
+    };
+    // everything step i reads — its bid row, the three trace values, the forecast floats of its observation — is requested one
+    // step AHEAD, before the stores of step i - 1 are issued: vmcnt retires in order, so a load issued behind a store waits for
+    // that store's acknowledgement (the first form of this loop did: one write latency per step, 5.3 us per step)
+    struct StepIn { float2 a[kPairPasses], f[kPairPasses]; float bc, bd, pf, lf, mf; };
+    auto fetch = [&](int i, int tt, bool rows, StepIn& in) {
+        load_bids(i, in.a, in.bc, in.bd);
+        const int tc = tt < BAT_EPISODE_STEPS ? tt : BAT_EPISODE_STEPS - 1;      // (a step after the end reads nothing it uses)
+        in.pf = price[tc]; in.lf = load[tc]; in.mf = moer[tc];
+        const float* lfc = lfc0 + tc + 2;
+        const float* mfc = mfc0 + tc + 2;
+#pragma unroll
+        for (int j = 0; j < kPairPasses; j++) {
+            float v[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int ii = 2 * (q + LPE * j) + h;
+                v[h] = 0.0f;
+                if (rows) {
+                    if (ii >= 5 + 2 * k && ii < 5 + 3 * k) v[h] = lfc[ii - (5 + 2 * k)];
+                    if (ii >= 6 + 3 * k && ii < 6 + 4 * k) v[h] = mfc[ii - (6 + 3 * k)];
+                }
+            }
+            in.f[j] = make_float2(v[0], v[1]);
+        }
+    };
+    const bool every_row = obs_traj != nullptr;
+    StepIn cur, nxt;
+    fetch(0, t, every_row || steps == 1 || t + 1 >= BAT_EPISODE_STEPS, cur);
+    double r = 0.0;
+    bool done = t >= BAT_EPISODE_STEPS;
+    for (int i = 0; i < steps; i++) {
+        if (t >= BAT_EPISODE_STEPS) {                  // steps after termination: no-ops, reward 0
+            r = 0.0;
+            done = true;
+            if (reward_traj && q == 0)
+                for (int j = i; j < steps; j++) reward_traj[(size_t)j * P.N + env] = 0.0;
+            break;
+        }
+        const int t1 = t + 1;
+        done = t1 >= BAT_EPISODE_STEPS;
+        const bool last = i + 1 == steps || done;
+        const bool want_row = every_row || last;
+        if (i + 1 < steps) fetch(i + 1, t1, every_row || i + 2 == steps || t1 + 1 >= BAT_EPISODE_STEPS, nxt);
+        const float pf = cur.pf, lf = cur.lf, mf = cur.mf;
+        const double p = (double)pf, m = (double)mf;
+        const bool sell = p >= (double)cur.bd, buy = p <= (double)cur.bc;
+        double x = 0.0, e1 = e;
+        if (sell && !buy) {
+            x = fmin(P.step_mwh, P.eta_d * e);
+            e1 = e - x / P.eta_d;
+        } else if (buy && !sell) {
+            x = -fmin(P.step_mwh, (P.cap - e) / P.eta_c);
+            e1 = e - P.eta_c * x;
+        }
+        e1 = fmin(fmax(e1, 0.0), P.cap);
+        r = p * x + P.pco2 * m * x;
+        if (done) r -= term_price * fmax(0.0, P.e0 - e1);
+        if (want_row) {
+            auto scalar = [&](int ii, float v) -> float {
+                if (ii == 0) return (float)t1;
+                if (ii == 1) return (float)e1;
+                if (ii == 2 + 2 * k) return (float)x;
+                if (ii == 3 + 2 * k) return pf;
+                if (ii == 4 + 2 * k) return lf;
+                if (ii == 5 + 3 * k) return mf;
+                return v;
+            };
+            float2* row_last = reinterpret_cast<float2*>(obs + (size_t)env * F);
+            float2* row_traj = obs_traj ? reinterpret_cast<float2*>(obs_traj + ((size_t)i * P.N + env) * F) : nullptr;
+#pragma unroll
+            for (int j = 0; j < kPairPasses; j++) {
+                const int pr = q + LPE * j;
+                float2 v = (pr >= 1 && pr <= k) ? cur.a[j] : cur.f[j];
+                v.x = scalar(2 * pr, v.x);
+                v.y = scalar(2 * pr + 1, v.y);
+                if (pr < F / 2) {
+                    if (row_traj) row_traj[pr] = v;
+                    if (last) row_last[pr] = v;
+                }
+            }
+        }
+        if (reward_traj && q == 0) reward_traj[(size_t)i * P.N + env] = r;
+        ret += r;
+        e = e1;
+        t = t1;
+        cur = nxt;
+    }
+    if (q == 0) {
+        P.energy[env] = e;
+        P.t[env] = t;
+        P.ret[env] = ret;
+        reward[env] = r;
+        terminated[env] = done ? 1 : 0;
+    }
+}
+
 __global__ void bat_metrics_kernel(BatParams P, double* out) {
     double se = 0.0, sr = 0.0, done = 0.0;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < P.N; e += gridDim.x * blockDim.x) {
@@ -285,6 +420,26 @@ int bat_step(bat_engine* e, const float* bids_dev, float* obs_dev, double* rewar
                        reward_dev, terminated_dev);
     HIP_TRY(hipGetLastError());
     e->env_steps += (unsigned long long)e->P.N;
+    return 0;
+}
+
+int bat_rollout(bat_engine* e, const float* bids_ring_dev, int32_t ring_len, int32_t steps, float* obs_dev, double* reward_dev,
+                uint8_t* terminated_dev, float* obs_traj_dev, double* reward_traj_dev) {
+    if (!e || !bids_ring_dev || !obs_dev || !reward_dev || !terminated_dev) return fail(-1, "bat_rollout: null argument");
+    if (ring_len < 1 || steps < 1) return fail(-1, "bat_rollout: ring_len and steps must be >= 1");
+    HIP_TRY(hipSetDevice(e->device));
+    // lanes per environment: 16 = the step kernel's geometry (default); 64 = a wavefront per environment, measured SLOWER
+    // (7.2 against 5.5 us per 16 384-environment step with a trajectory, 3.0 against 1.6 without): the loop is not short of
+    // loops in flight.  BAT_ROLLOUT_LPE=64 selects it (measurements).
+    static const int lpe = getenv("BAT_ROLLOUT_LPE") ? atoi(getenv("BAT_ROLLOUT_LPE")) : 16;
+    if (lpe == 16)
+        hipLaunchKernelGGL(bat_rollout_kernel<16>, dim3((e->P.N + 15) / 16), dim3(256), 0, e->stream, e->P, bids_ring_dev, ring_len, steps,
+                           obs_dev, reward_dev, terminated_dev, obs_traj_dev, reward_traj_dev);
+    else
+        hipLaunchKernelGGL(bat_rollout_kernel<64>, dim3((e->P.N + 3) / 4), dim3(256), 0, e->stream, e->P, bids_ring_dev, ring_len, steps,
+                           obs_dev, reward_dev, terminated_dev, obs_traj_dev, reward_traj_dev);
+    HIP_TRY(hipGetLastError());
+    e->env_steps += (unsigned long long)e->P.N * (unsigned long long)steps;
     return 0;
 }
 

@@ -90,3 +90,61 @@ def test_battery_lean_stepper_equals_step():
         np.testing.assert_allclose(m0[key], m1[key], rtol=1e-12, err_msg=key)
     for env in envs:
         env.close()
+
+
+@pytest.mark.parametrize('trajectory', [True, False])
+def test_battery_rollout_equals_the_loop_of_steps_and_the_oracle(trajectory):
+    """bat_rollout (T steps in one launch, state in registers, bids from a device-resident ring) == T calls of bat_step:
+    every observation / reward of the trajectory, the last outputs, the state and the running return — bit for bit — in
+    chunks that start mid-episode and run past its end; and the whole episode against the scalar oracle."""
+    import torch
+    from oracle.binding import OracleBattery
+    from sustaingym_amd.battery import BatteryDispatchVectorEnv, synthetic_market_traces
+    N, k, R = 1000, 36, 7                                      # N not a multiple of 16: a ragged last workgroup
+    tr = synthetic_market_traces(64, k, seed=11)
+    envs = []
+    for _ in range(2):
+        env = BatteryDispatchVectorEnv(N, k, bank_slots=64, output='torch')
+        env.upload_traces(tr)
+        env.reset(np.arange(N) % 64)
+        envs.append(env)
+    g = torch.Generator(device='cuda'); g.manual_seed(9)
+    ring = (torch.rand((R, N, 2 * k), device='cuda', generator=g) * 90).contiguous()
+    done = 0
+    all_obs, all_rew = [], []
+    for steps in (1, 100, 150, 60):                            # 1 + 100 + 150 = 251; the last chunk runs 23 steps past the end
+        res = envs[0].rollout(ring[[(done + i) % R for i in range(R)]].contiguous(), steps, trajectory=trajectory)   # ring rotated to start at `done`
+        o_last, r_last, t_last = [x.clone() for x in res[:3]]
+        obs_steps, rew_steps = [], []
+        for i in range(steps):
+            o, r, t = envs[1].step(ring[(done + i) % R])
+            obs_steps.append(o.clone()); rew_steps.append(r.clone())
+        torch.cuda.synchronize()
+        live = min(steps, max(0, 288 - done))
+        assert torch.equal(o_last, obs_steps[-1]) and torch.equal(r_last, rew_steps[-1]) and torch.equal(t_last, t), steps
+        if trajectory:
+            ot, rt = res[3]
+            assert torch.equal(rt, torch.stack(rew_steps)), steps
+            assert torch.equal(ot[:live], torch.stack(obs_steps[:live])), steps
+            all_obs.append(ot[:live].cpu().numpy()); all_rew.append(rt[:live].cpu().numpy())
+        e0, t0 = envs[0].state()
+        e1, t1 = envs[1].state()
+        assert np.array_equal(e0, e1) and np.array_equal(t0, t1)
+        done += steps
+    m0, m1 = envs[0].read_metrics(), envs[1].read_metrics()
+    for key in m0:
+        np.testing.assert_allclose(m0[key], m1[key], rtol=1e-12, err_msg=key)
+    if trajectory:                                             # the trajectory against the oracle, a sample of environments
+        obs_all, rew_all = np.concatenate(all_obs), np.concatenate(all_rew)
+        assert obs_all.shape[0] == 288
+        ring_h = ring.cpu().numpy()
+        for i in (0, 17, 63, 64, 999):
+            o = OracleBattery(k)
+            s = i % 64
+            o.reset(tr['price'][s], tr['load'][s], tr['load_fc'][s], tr['moer'][s], tr['moer_fc'][s], tr['terminal_price'][s])
+            for t in range(288):
+                oo, r, d = o.step(ring_h[t % R, i])
+                assert np.array_equal(obs_all[t, i], oo), (i, t)
+                assert abs(rew_all[t, i] - r) <= 1e-12 * max(1.0, abs(r))
+    for env in envs:
+        env.close()
