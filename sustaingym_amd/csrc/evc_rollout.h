@@ -48,7 +48,12 @@ struct RolloutLds {
     unsigned char st_info[64];
     LdsRare rare;                                  // Params fields of the rarely taken projection branch
     int noconv[4];                                 // per wavefront: bit r = the solve of row r did not converge
+    // warm start of the general iteration (greedy policy; evc_solver.h SolveWarm): the multipliers it ended with for the row's
+    // environment, and the period (loop count + 1) they belong to — used only in the very next period
+    double zwarm[4][4][16][2];
+    int warm_tag[4][4];
 };
+static_assert(EVC_MAX_CONSTRAINTS >= 16, "the quad geometry handles up to 16 rows");
 
 constexpr unsigned kRolloutKernargBytes = (unsigned)((((sizeof(Params) + alignof(RolloutIO) - 1) / alignof(RolloutIO)) * alignof(RolloutIO) + sizeof(RolloutIO) + 7u) & ~(size_t)7u);
 
@@ -65,6 +70,8 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
     RolloutLds& S = *(RolloutLds*)(LdsImage*)(size_t)(unsigned)rfl((int)lds);
     const int w = rfl((int)wv);
     unsigned mask = (unsigned)rfl((int)rows);
+    const unsigned tag = mask >> 8;                // 0: no warm start (policies whose actions are redrawn every period)
+    mask &= 0xffu;
     const int lane = (int)__lane_id();
 #ifndef EVC_NO_ROWCONE             /* variant builds only: the round-3 form (every row through the wave-per-environment solver) */
     {
@@ -113,7 +120,14 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
         ln.b = (mask & 16u) ? (double)S.act_img[w][r][lane] * Consts::ACTION_SCALE_FACTOR : Consts::ACTION_SCALE_FACTOR;
         ln.y = 0.0;
         bool noconv;
-        const double y = solve_projection(P, L, lnet, ln, lane, noconv);
+        double y;
+        if (tag != 0u && P.m <= 16) {
+            SolveWarm W{S.zwarm[w][r], S.warm_tag[w][r] == (int)tag - 1 && tag > 1u, false};
+            y = solve_projection(P, L, lnet, ln, lane, noconv, &W);
+            if (lane == 0) S.warm_tag[w][r] = W.stored ? (int)tag : 0;
+        } else {
+            y = solve_projection(P, L, lnet, ln, lane, noconv);
+        }
         S.img[w][r][lane].h_or_y = y;
         if (noconv && lane == 0) S.noconv[w] |= 1 << r;
         SOLVER_SYNC();
@@ -160,6 +174,7 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
         st_info[s] = (unsigned char)((unsigned)gid | ((unsigned)((P.cc_mask >> s) & 1ull) << 7));
     }
     if (tid < 4u) S.noconv[tid] = 0;
+    if (tid < 16u) S.warm_tag[tid >> 2][tid & 3u] = 0;
 #pragma unroll
     for (int j = 0; j < kSlots; j++) S.img[wv][row][j * 16 + q].h_or_y = 0.0;
     stage_rare(S.rare, P);
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                         if (solve_me && valid[c]) img_row[st[c]].h_or_y = quad_demand_cap(dep[c], rem[c]);
                     const unsigned rows = ((solve_mask & 0xffffull) ? 1u : 0u) | ((solve_mask & 0xffff0000ull) ? 2u : 0u) |
                                           ((solve_mask & 0xffff00000000ull) ? 4u : 0u) | ((solve_mask >> 48) ? 8u : 0u) |
-                                          (KIND != 0 ? 16u : 0u);
+                                          (KIND != 0 ? 16u : 0u) | (KIND == 0 ? (unsigned)(step + 1) << 8 : 0u);
                     lds_sync();
                     rollout_solve_rows((unsigned)(size_t)(__attribute__((address_space(3))) void*)&S, wv, rows);
                     lds_sync();

@@ -523,19 +523,28 @@ __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, 
 // returns the projected (and, where the solver moved it, tie-snapped) value of the lane's station.  `noconv` is set when
 // neither the Newton iteration nor the proximal-gradient safeguard reached the tolerance (EVC_STATUS_PROJ_NOCONV).
 // Shared by solve_env below (slow kernel, in-kernel drain) and by the fused rollout kernel (evc_rollout.h).
+// Warm start (round 4, used by the fused rollout kernel): `warm` = the multipliers the general iteration ended with for THIS
+// environment one period earlier ([m][2] in LDS), `warm->valid` says they are.  Under a policy whose actions hardly change from
+// period to period (greedy) the dual optimum hardly moves either: the general iteration then starts beside it — the relaxation
+// front (exact rows, filling, cone chain: ~50 000 cycles spent before the iteration even begins on a problem with many active
+// rows) is skipped and two or three Newton iterations remain of seven.  The iteration activates and deactivates rows by itself
+// (solver_trial), its convergence test covers every row, so a poor start costs time, never correctness.
+struct SolveWarm { double (*z)[2]; bool valid; bool stored; };
 __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L, const LaneNet& lnet, SolverLane& ln, int lane,
-                                                   bool& noconv) {
+                                                   bool& noconv, SolveWarm* warm = nullptr) {
     const int m = P.m, G = P.G;
     noconv = false;
     [[maybe_unused]] long long c0 = SOLVER_CLK();
-    if (lane < m) { L.z[lane][0] = 0.0; L.z[lane][1] = 0.0; }
+    const bool warm_start = warm != nullptr && warm->valid;
+    if (lane < m) { L.z[lane][0] = warm_start ? warm->z[lane][0] : 0.0; L.z[lane][1] = warm_start ? warm->z[lane][1] : 0.0; }
     SOLVER_SYNC();
+    if (warm) warm->stored = false;
 
     // (a) the screen of the streaming kernel may have been merely inconclusive: exact test of
     //     the box clip; (b) class caps (pod breakers) violated: closed-form water-filling, exact if
     //     every row holds afterwards (relaxation argument)
     bool settled = false;
-    {
+    if (!warm_start) {
         const double y0 = fmin(ln.b, ln.h);
         const ExactRows e0 = exact_rows_worst(P, L.net, lnet, lane, y0);
         ln.y = y0;
@@ -798,6 +807,11 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
     if (!converged && !last_ok) {                 // rare: the Newton stalled — globally convergent fallback
         converged = solver_proximal_gradient(P, L, ln, lane);
         if (!converged) noconv = true;
+    }
+    if (warm && !settled && !noconv) {            // the general iteration ran: its multipliers are next period's start
+        if (lane < m) { warm->z[lane][0] = L.z[lane][0]; warm->z[lane][1] = L.z[lane][1]; }
+        warm->stored = true;
+        SOLVER_SYNC();
     }
     // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
     // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
