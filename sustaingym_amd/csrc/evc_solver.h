@@ -395,7 +395,7 @@ __device__ __forceinline__ ExactRows exact_rows_worst(const Params& P, const Lds
 
 template <int R>
 __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, double h, const int (&rows)[R],
-                                          double (&z)[2 * R], double& yout) {
+                                          double (&z)[2 * R], double& yout, bool all_warm = false) {
     constexpr int D = 2 * R;
     double cf[D], rmag[R];
 #pragma unroll
@@ -431,7 +431,7 @@ __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, 
             free_set = now_free;
             have_K = true;
         }
-        if (it == 0) {
+        if (it == 0 && !all_warm) {
             // the row without a multiplier: alone, the first-order size along its w; beside an active row, tiny
             const int a0 = D - 2;
             const double nw = sqrt(w[a0] * w[a0] + w[a0 + 1] * w[a0 + 1]);
@@ -539,11 +539,49 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
     if (lane < m) { L.z[lane][0] = warm_start ? warm->z[lane][0] : 0.0; L.z[lane][1] = warm_start ? warm->z[lane][1] : 0.0; }
     SOLVER_SYNC();
     if (warm) warm->stored = false;
+    bool warm_settled = false;
+#ifndef EVC_ABL_NO_WAVE_CONE
+    if (warm_start) {
+        // the rows that carried a multiplier one period ago, if there are at most three: the in-register Newton from those
+        // multipliers (every row warm: no first-order start), accepted only if every row and cap holds at its optimum
+        const unsigned long long act = __ballot(lane < m && (L.z[lane < m ? lane : 0][0] != 0.0 || L.z[lane < m ? lane : 0][1] != 0.0));
+        const int na = __popcll(act);
+        double yw = 0.0;
+        bool got = false;
+        if (na >= 1 && na <= 3) {
+            int rr[3] = {0, 0, 0};
+            double zz[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            unsigned long long a2 = act;
+            for (int i = 0; i < na; i++) {
+                rr[i] = __builtin_ctzll(a2);
+                a2 &= a2 - 1ull;
+                zz[2 * i] = L.z[rr[i]][0];
+                zz[2 * i + 1] = L.z[rr[i]][1];
+            }
+            if (na == 1) { const int r1[1] = {rr[0]}; double z1[2] = {zz[0], zz[1]}; got = wave_cone<1>(L.net, lnet.gid, ln.b, ln.h, r1, z1, yw, true);
+                           zz[0] = z1[0]; zz[1] = z1[1]; }
+            else if (na == 2) { const int r2[2] = {rr[0], rr[1]}; double z2[4] = {zz[0], zz[1], zz[2], zz[3]}; got = wave_cone<2>(L.net, lnet.gid, ln.b, ln.h, r2, z2, yw, true);
+                                for (int i = 0; i < 4; i++) zz[i] = z2[i]; }
+            else { const int r3[3] = {rr[0], rr[1], rr[2]}; got = wave_cone<3>(L.net, lnet.gid, ln.b, ln.h, r3, zz, yw, true); }
+            if (got) {
+                const ExactRows ew = exact_rows_worst(P, L.net, lnet, lane, yw);
+                if (ew.viol == 0ull && ew.cap_viol == 0u) {
+                    ln.y = yw;
+                    warm_settled = true;
+                    if (lane == 0)
+                        for (int i = 0; i < na; i++) { warm->z[rr[i]][0] = zz[2 * i]; warm->z[rr[i]][1] = zz[2 * i + 1]; }
+                    warm->stored = true;
+                    SOLVER_SYNC();
+                }
+            }
+        }
+    }
+#endif
 
     // (a) the screen of the streaming kernel may have been merely inconclusive: exact test of
     //     the box clip; (b) class caps (pod breakers) violated: closed-form water-filling, exact if
     //     every row holds afterwards (relaxation argument)
-    bool settled = false;
+    bool settled = warm_settled;
     if (!warm_start) {
         const double y0 = fmin(ln.b, ln.h);
         const ExactRows e0 = exact_rows_worst(P, L.net, lnet, lane, y0);
@@ -809,6 +847,7 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
         if (!converged) noconv = true;
     }
     if (warm && !settled && !noconv) {            // the general iteration ran: its multipliers are next period's start
+        // (a start settled by the in-register Newton above has stored its own)
         if (lane < m) { warm->z[lane][0] = L.z[lane][0]; warm->z[lane][1] = L.z[lane][1]; }
         warm->stored = true;
         SOLVER_SYNC();
