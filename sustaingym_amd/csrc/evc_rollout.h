@@ -92,7 +92,12 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
             h[j] = valid ? S.img[w][row][st].h_or_y : 0.0;
             b[j] = !valid ? 0.0 : (mask & 16u) ? (double)S.act_img[w][row][st] * Consts::ACTION_SCALE_FACTOR : Consts::ACTION_SCALE_FACTOR;
         }
-        const bool settled = quad_project(S.rare.G, S.rare.class_cap, S.rare.simple_rows, P.tie_counters, S.net, q, (unsigned)P.m, row, on, st_gid, is_cc, b, h, y);
+        const bool warm_on = tag != 0u && P.m <= 16;
+        const bool warm_ok = warm_on && tag > 1u && S.warm_tag[w][row] == (int)tag - 1;
+        bool stored = false;
+        const bool settled = quad_project(S.rare.G, S.rare.class_cap, S.rare.simple_rows, P.tie_counters, S.net, q, (unsigned)P.m, row, on, st_gid, is_cc, b, h, y,
+                                          warm_on ? S.zwarm[w][row] : nullptr, warm_ok, &stored);
+        if (warm_on && on && settled && q == 0u) S.warm_tag[w][row] = stored ? (int)tag : 0;
         if (settled) {
 #pragma unroll
             for (int j = 0; j < kSlots; j++)

@@ -74,7 +74,8 @@ __device__ __forceinline__ RowExact quad_exact_rows_worst(int G, const double* c
 template <int R>
 __device__ __forceinline__ bool quad_cone(const LdsNet& net, unsigned row, bool on, const int (&st_gid)[kSlots],
                                           const double (&b)[kSlots], const double (&h)[kSlots], const int (&rows)[R],
-                                          double (&z)[2 * R], double (&yout)[kSlots]) {
+                                          double (&z)[2 * R], double (&yout)[kSlots], bool warm = false) {
+    // warm (row-uniform): every multiplier of this row's environment is given (last period's optimum): no first-order start
     constexpr int D = 2 * R;
     double cf[D][kSlots], rmag[R];
 #pragma unroll
@@ -130,19 +131,20 @@ __device__ __forceinline__ bool quad_cone(const LdsNet& net, unsigned row, bool 
                 }
             have_K = true;
         }
+        const bool starting = it == 0 && !warm;          // this row only places its new multiplier in this pass
         if (it == 0) {
             // the row without a multiplier: alone, the first-order size along its w; beside an active row, tiny
             const int a0 = D - 2;
             const double nw = sqrt(w[a0] * w[a0] + w[a0 + 1] * w[a0 + 1]);
-            if (!(nw > rmag[R - 1])) run = false;                       // (not violated after all: the general path decides)
+            if (starting && !(nw > rmag[R - 1])) run = false;           // (not violated after all: the general path decides)
             const double wh0 = w[a0] / nw, wh1 = w[a0 + 1] / nw;
             double lam = 1e-6;
             if (R == 1) {
                 const double curv = wh0 * (K[0][0] * wh0 + K[0][1] * wh1) + wh1 * (K[0][1] * wh0 + K[1][1] * wh1);
                 if (curv > 0.0) lam = fmax((nw - rmag[0]) / curv, 1e-6);
             }
-            if (run) { z[a0] = lam * wh0; z[a0 + 1] = lam * wh1; }
-            continue;
+            if (run && starting) { z[a0] = lam * wh0; z[a0 + 1] = lam * wh1; }
+            if (__ballot(run && warm) == 0ull) continue;                // no warm row in this wavefront: nothing else to do in pass 0
         }
         double zh[D], g[D], rn[R];
         bool conv = true;
@@ -157,7 +159,7 @@ __device__ __forceinline__ bool quad_cone(const LdsNet& net, unsigned row, bool 
             const double lim = Consts::PROJ_TOL_KKT * rmag[r];
             conv = conv && g[2 * r] * g[2 * r] + g[2 * r + 1] * g[2 * r + 1] <= lim * lim;
         }
-        if (run && conv) {
+        if (run && conv && !starting) {
 #pragma unroll
             for (int j = 0; j < kSlots; j++) yout[j] = y[j];
             ok = true;
@@ -204,17 +206,17 @@ __device__ __forceinline__ bool quad_cone(const LdsNet& net, unsigned row, bool 
             for (int u = a + 1; u < D; u++) t -= B[a][u] * d[u];
             d[a] = t * inv[a];
         }
-        if (!good) run = false;
+        if (!good && !starting) run = false;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const double t0 = z[2 * r] + d[2 * r], t1 = z[2 * r + 1] + d[2 * r + 1];
-            if (!(t0 * z[2 * r] + t1 * z[2 * r + 1] > 0.0)) run = false;     // the row would leave the active set
+            if (!starting && !(t0 * z[2 * r] + t1 * z[2 * r + 1] > 0.0)) run = false;     // the row would leave the active set
         }
-        if (run) {
+        if (run && !starting) {
 #pragma unroll
             for (int a = 0; a < D; a++) z[a] += d[a];
         }
-        mu = fmax(mu * 0.25, 1e-12);
+        if (!starting) mu = fmax(mu * 0.25, 1e-12);
     }
     return ok;
 }
@@ -265,16 +267,46 @@ __device__ __forceinline__ void quad_waterfill_bh(bool on, int g, const int (&st
 // by water-filling (exact if every row holds afterwards) -> one violated cap's row + the worst remaining row at once, or the
 // chain one cone row -> two.  Returns (row-uniform) whether the row is
 // settled; y then holds the projection (values the solver moved are tie-snapped like solve_projection's).
+// zw / warm_ok (round 4, greedy policy): zw = this row's [m][2] multipliers of one period ago (LDS), warm_ok (row-uniform) says they
+// are valid.  A row with one or two rows active then goes straight to the Newton on those rows from those multipliers — no
+// filling, no chain; a row the warm solve does not settle is left to the general path.  Whatever settles a row with at most
+// two active rows (a filled cap counts: its multiplier is nu cf / |cf|^2 on its simple row) leaves its multipliers in zw and
+// returns stored = true; zw may be null.
 __device__ __forceinline__ bool quad_project(int G, const double* class_cap, unsigned simple_rows, unsigned long long* tie_counters, const LdsNet& net,
                                              unsigned q, unsigned m, unsigned row, bool on, const int (&st_gid)[kSlots],
                                              const bool (&is_cc)[kSlots], const double (&b)[kSlots], const double (&h)[kSlots],
-                                             double (&y)[kSlots]) {
+                                             double (&y)[kSlots], double (*zw)[2] = nullptr, bool warm_ok = false, bool* stored = nullptr) {
     double y0[kSlots];
 #pragma unroll
     for (int j = 0; j < kSlots; j++) { y0[j] = fmin(b[j], h[j]); y[j] = y0[j]; }
+    // what the row solved with, for the next period: up to two rows and their multipliers (-1: none)
+    int keep_row[2] = {-1, -1};
+    double keep_z[4] = {0.0, 0.0, 0.0, 0.0};
+    bool keep = false;
+    // warm rows: the rows that carried a multiplier one period ago
+    int wrow[2] = {-1, -1};
+    double wz[4] = {0.0, 0.0, 0.0, 0.0};
+    bool warm1 = false, warm2 = false;
+    if (zw != nullptr && __ballot(on && warm_ok) != 0ull) {
+        const bool nzq = q < m && (zw[q < m ? q : 0][0] != 0.0 || zw[q < m ? q : 0][1] != 0.0);
+        const unsigned act = (unsigned)(__ballot(nzq) >> (row * 16u)) & 0xffffu;
+        const int na = __popc(act);
+        if (on && warm_ok && na >= 1 && na <= 2) {
+            wrow[0] = (int)__builtin_ctz(act);
+            wz[0] = zw[wrow[0]][0]; wz[1] = zw[wrow[0]][1];
+            if (na == 2) {
+                wrow[1] = (int)__builtin_ctz(act & (act - 1u));
+                wz[2] = zw[wrow[1]][0]; wz[3] = zw[wrow[1]][1];
+                warm2 = true;
+            } else {
+                warm1 = true;
+            }
+        }
+    }
+    const bool warm_row = warm1 || warm2;
     const RowExact e0 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y0);
-    bool settled = on && e0.viol == 0u && e0.cap_viol == 0u;
-    bool open = on && !settled;
+    bool settled = on && !warm_row && e0.viol == 0u && e0.cap_viol == 0u;
+    bool open = on && !warm_row && !settled;
     bool d2 = false;                               // a pair of rows to solve together, from the filling or from the chain
     int pair[2] = {-1, -1};
     double zp[2] = {0.0, 0.0};
@@ -296,16 +328,18 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
         }
         settled = settled || okw;
         open = open && !okw;
-        // Caps filled, a row still violated: the caps' own rows and the worst remaining row together, the caps' multipliers
-        // taken from the filling (a class shifted by nu has z_c = nu cf / |cf|^2 on its simple row c) — solve_projection's (b2).
+        // The caps' own rows and multipliers, from the filling (a class shifted by nu has z_c = nu cf / |cf|^2 on its simple
+        // row c): for a row the filling settled they are what the next period starts from; where a row is still violated, the
+        // caps' rows and the worst remaining row are solved together (solve_projection's (b2)).
         const bool direct = fill && !okw && __popc(e0.cap_viol) <= 2 && ew.worst >= 0;
-        if (__ballot(direct) != 0ull) {
+        const bool capinfo = (direct || (okw && zw != nullptr)) && __popc(e0.cap_viol) <= 2;
+        if (__ballot(capinfo) != 0ull) {
             int crow[2] = {-1, -1};
             double zc[4] = {0.0, 0.0, 0.0, 0.0};
             int nc = 0;
-            bool usable = direct;
+            bool usable = capinfo;
             for (int g = 0; g < G; g++) {
-                const bool mine = direct && ((e0.cap_viol >> g) & 1u);
+                const bool mine = capinfo && ((e0.cap_viol >> g) & 1u);
                 if (__ballot(mine) == 0ull) continue;
                 const bool is_row = q < m && ((simple_rows >> q) & 1u) && (net.Mre[g][q] != 0.0 || net.Mim[g][q] != 0.0);
                 const unsigned rb = (unsigned)(__ballot(is_row) >> (row * 16u)) & 0xffffu;
@@ -327,7 +361,13 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
                     }
                 }
             }
-            usable = usable && nc >= 1 && ew.worst != crow[0] && ew.worst != crow[1];
+            if (okw && usable && nc >= 1) {
+                keep = true;
+                keep_row[0] = crow[0]; keep_row[1] = crow[1];
+#pragma unroll
+                for (int a = 0; a < 4; a++) keep_z[a] = zc[a];
+            }
+            usable = usable && direct && nc >= 1 && ew.worst != crow[0] && ew.worst != crow[1];
             // (three rows — both pods beside a feeder row — in this geometry cost every copy of the period's body its registers:
             // scratch 444 -> 1584 B, Caltech GMM greedy 57 -> 78 us per period, measured; those rows go to the general path)
             d2 = usable && nc == 1;
@@ -335,39 +375,60 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
             open = open && !d2;                    // (a direct attempt that fails goes to the general path, not through the chain)
         }
     }
+    if (settled && !keep && e0.cap_viol == 0u) keep = true;       // nothing binds: next period starts from zero multipliers
     bool go2 = false;
-    if (__ballot(open) != 0ull) {
-        const int r1[1] = {e0.worst};
-        double z1[2] = {0.0, 0.0}, y1[kSlots];
+    const bool on1 = (open && e0.worst >= 0) || warm1;
+    if (__ballot(on1) != 0ull) {
+        const int r1[1] = {warm1 ? wrow[0] : e0.worst};
+        double z1[2] = {warm1 ? wz[0] : 0.0, warm1 ? wz[1] : 0.0}, y1[kSlots];
 #pragma unroll
         for (int j = 0; j < kSlots; j++) y1[j] = 0.0;
-        const bool c1 = quad_cone<1>(net, row, open && e0.worst >= 0, st_gid, b, h, r1, z1, y1);
+        const bool c1 = quad_cone<1>(net, row, on1, st_gid, b, h, r1, z1, y1, warm1);
         const RowExact e1 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y1);
         const bool ok1 = c1 && e1.viol == 0u && e1.cap_viol == 0u;
         if (ok1) {
 #pragma unroll
             for (int j = 0; j < kSlots; j++) y[j] = y1[j];
+            keep = true;
+            keep_row[0] = r1[0]; keep_row[1] = -1;
+            keep_z[0] = z1[0]; keep_z[1] = z1[1];
         }
         settled = settled || ok1;
-        go2 = c1 && !ok1 && e1.viol != 0u && e1.worst != e0.worst && e1.worst >= 0;
-        if (go2) { pair[0] = e0.worst; pair[1] = e1.worst; zp[0] = z1[0]; zp[1] = z1[1]; }
+        go2 = c1 && !ok1 && e1.viol != 0u && e1.worst != r1[0] && e1.worst >= 0;
+        if (go2) { pair[0] = r1[0]; pair[1] = e1.worst; zp[0] = z1[0]; zp[1] = z1[1]; }
     }
-    // ONE two-row solve for both sources of a pair (one inlined copy of quad_cone<2>: registers)
-    const bool want2 = d2 || go2;
+    // ONE two-row solve for every source of a pair (one inlined copy of quad_cone<2>: registers)
+    const bool want2 = d2 || go2 || warm2;
     if (__ballot(want2) != 0ull) {
-        const int r2[2] = {pair[0], pair[1]};
-        double z2[4] = {zp[0], zp[1], 0.0, 0.0}, y2[kSlots];
+        const int r2[2] = {warm2 ? wrow[0] : pair[0], warm2 ? wrow[1] : pair[1]};
+        double z2[4] = {warm2 ? wz[0] : zp[0], warm2 ? wz[1] : zp[1], warm2 ? wz[2] : 0.0, warm2 ? wz[3] : 0.0}, y2[kSlots];
 #pragma unroll
         for (int j = 0; j < kSlots; j++) y2[j] = 0.0;
-        const bool c2 = quad_cone<2>(net, row, want2, st_gid, b, h, r2, z2, y2);
+        const bool c2 = quad_cone<2>(net, row, want2, st_gid, b, h, r2, z2, y2, warm2);
         const RowExact e2 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y2);
         const bool ok2 = c2 && e2.viol == 0u && e2.cap_viol == 0u;
         if (ok2) {
 #pragma unroll
             for (int j = 0; j < kSlots; j++) y[j] = y2[j];
+            keep = true;
+            keep_row[0] = r2[0]; keep_row[1] = r2[1];
+#pragma unroll
+            for (int a = 0; a < 4; a++) keep_z[a] = z2[a];
         }
         settled = settled || ok2;
     }
+    // the multipliers the row settled with, for the next period
+    const bool st = zw != nullptr && settled && keep;
+    if (__ballot(st) != 0ull) {
+        if (st && q < m) {
+            double v0 = 0.0, v1 = 0.0;
+            if ((int)q == keep_row[0]) { v0 = keep_z[0]; v1 = keep_z[1]; }
+            if ((int)q == keep_row[1]) { v0 = keep_z[2]; v1 = keep_z[3]; }
+            zw[q][0] = v0;
+            zw[q][1] = v1;
+        }
+    }
+    if (stored) *stored = st;
     // Tie snap: values the solver moved go to the 2^-16 A grid, exactly as solve_projection does it
     if (__ballot(settled) != 0ull) {
 #pragma unroll
