@@ -342,6 +342,51 @@ def test_vector_env_torch_output_stays_on_device():
 
 
 @pytest.mark.gpu
+def test_vector_env_pipeline2_closed_loop_equals_the_default_form():
+    """EVChargingVectorEnv(output='torch', pipeline=2) — steps as two half-batch launches, NOT joined by step() — driven by a
+    closed-loop policy (the caller's greedy from obs['demands']) computed per half on that half's stream
+    (venv.pipeline_halves()): rewards, observations and terminal observations over an episode boundary equal the default
+    one-launch-per-step vector env's, bit for bit.  65 536 environments: the smallest batches the engine splits are 32 768."""
+    import torch
+    from sustaingym_amd.event_generation import DeviceGMMTraceGenerator
+    N = 32768
+    envs = [EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2019', seed=4), num_envs=N, output='torch', pipeline=p)
+            for p in (1, 2)]
+    obs = [e.reset(seed=4)[0] for e in envs]
+    n = envs[0].num_stations
+    acts = [torch.zeros((N, n), dtype=torch.float32, device='cuda') for _ in envs]
+    halves = envs[1].pipeline_halves()
+    main = torch.cuda.current_stream()
+    ret = [torch.zeros(N, dtype=torch.float64, device='cuda') for _ in envs]
+    for t in range(300):
+        torch.sign(obs[0]['demands'], out=acts[0])
+        o, r, term, _, info = envs[0].step(acts[0])
+        ret[0] += r
+        for sl, st in halves:
+            with torch.cuda.stream(st):
+                torch.sign(obs[1]['demands'][sl], out=acts[1][sl])
+        o2, r2, term2, _, info2 = envs[1].step(acts[1])
+        for sl, st in halves:                                  # per-half consumers stay on the half's stream
+            with torch.cuda.stream(st):
+                ret[1][sl] += r2[sl]
+        if t in (0, 150, 286, 287, 288, 299):
+            envs[1].join()
+            torch.cuda.synchronize()
+            assert torch.equal(r, r2) and torch.equal(term, term2), t
+            for key in o:
+                assert torch.equal(o[key], o2[key]), (key, t)
+            if t == 287:
+                for key in o:
+                    assert torch.equal(info['final_observation'][key], info2['final_observation'][key]), key
+    envs[1].join()
+    torch.cuda.synchronize()
+    assert torch.equal(ret[0], ret[1])
+    assert envs[1]._engine.pipelined_steps() >= 290            # the boundary step's bank refill joins; the steps are split
+    for e in envs:
+        e.close()
+
+
+@pytest.mark.gpu
 def test_vector_env_batched_generator_matches_oracle_over_a_boundary():
     """EVChargingVectorEnv fed by one BatchedGMMTraceGenerator: episodes drawn in bulk (the refill
     on a worker thread), two full episodes stepped; every environment is replayed by the oracle
