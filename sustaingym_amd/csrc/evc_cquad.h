@@ -275,6 +275,38 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         bool live = ev && !after_done;
         const int t1 = t + 1;
         const bool more = __ballot(A > 16u) != 0ull;            // wave-uniform: entry slots 1..3 in use
+        // Round 4 — second-level loads requested as soon as the scalars are in (kEarly: the projecting kernels, which have the
+        // registers at 3 wavefronts per SIMD; the non-projecting kernel at 4 per SIMD spills on them: 25.55 -> 26.3 us as one
+        // launch, measured, so it keeps the late form).  (i) The session record at the cursor and the arrival time of the one
+        // behind it: whether an EV arrives this period is known from the scalars alone (next_arrival), and the plug-in section
+        // is a microsecond of work away — its two dependent round trips were exposed in the middle of the body (0.11 arrivals
+        // per environment-step: one quad in three).  (ii) The MOER row of the period (reward, observation), formerly issued
+        // after the charge section to spare four VGPRs under the 128-register cap.  Same-box A/B, three interleaved pairs:
+        // (i) 23.17 -> 22.39 us per step pipelined, 26.79 -> 26.38 as one launch, GMM days 32.9 -> 32.05 / 45.5 -> 44.6;
+        // (i)+(ii) 22.52 -> 22.29 / 26.32 -> 26.06.
+        constexpr bool kEarly = PROJECT;
+        double moer_now0 = 0.0;
+        float mo0[3] = {0.0f, 0.0f, 0.0f};
+        v2u sv0 = {0u, 0u};
+        double rq0 = 0.0;
+        unsigned nx0 = 0u;
+        if constexpr (kEarly) {
+            const unsigned mrow0 = live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) : 0u;
+            moer_now0 = buf_ld_f64(r_hist, live ? mrow0 * 8u : kOob);
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const unsigned idx = (unsigned)p * 16u + q;             // position in [forecast | prev | ts]
+                const unsigned col = idx < k ? idx + 1u : 0u;
+                const unsigned o_moer = P.off_moer + (mrow0 * EVC_MOER_COLS + col) * 4u;
+                const unsigned o_ts = P.off_ts + (unsigned)t1 * 4u;
+                mo0[p] = buf_ld_f32(r_win, (live && idx <= k + 1u) ? (idx <= k ? o_moer : o_ts) : kOob);
+            }
+            const bool pend0 = live && next_arrival <= t1 && cursor < n_sessions;
+            const unsigned sidx0 = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
+            sv0 = buf_ld_v2(r_sess, pend0 ? sidx0 * 8u : kOob);
+            rq0 = buf_ld_f64(r_req, pend0 ? sidx0 * 8u : kOob);
+            nx0 = buf_ld_u32(r_sess, (pend0 && cursor + 1 < n_sessions) ? (sidx0 + 1u) * 8u : kOob);
+        }
 #ifdef EVC_PREFETCH_EARLY          /* measurement builds: the next quad's rows requested at the top of the iteration */
         quad_next = take_quad();
         if (quad_next >= 0) nxt = issue(quad_next);
@@ -500,9 +532,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 
         // MOER loads for t1 (row-uniform addresses); issued here rather than at the top of the iteration: the values are
         // only stored at its end, and four VGPRs fewer alive through the charge section are worth 0.8 us per step
+        double moer_now = moer_now0;
+        float mo[3] = {mo0[0], mo0[1], mo0[2]};
+        if constexpr (!kEarly) {
         const unsigned mrow = live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) : 0u;
-        const double moer_now = buf_ld_f64(r_hist, live ? mrow * 8u : kOob);
-        float mo[3];
+        moer_now = buf_ld_f64(r_hist, live ? mrow * 8u : kOob);
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             const unsigned idx = (unsigned)p * 16u + q;                 // position in [forecast | prev | ts]
@@ -513,14 +547,18 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             const unsigned o = idx <= k ? o_moer : o_ts;
             mo[p] = buf_ld_f32(r_win, (live && idx <= k + 1u) ? o : kOob);
         }
+        }
 
         if (live) t = t1;
         unsigned long long arrived = 0ull;                               // stations plugged in this pass
         bool pending = live && next_arrival <= t1 && cursor < n_sessions;
+        bool first_pass = kEarly;                   // the first record of the period was requested at the top of the iteration
         while (__ballot(pending) != 0ull) {
             const unsigned sidx = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
-            const v2u sv = buf_ld_v2(r_sess, pending ? sidx * 8u : kOob);
-            const double rq = buf_ld_f64(r_req, pending ? sidx * 8u : kOob);
+            v2u sv;
+            double rq;
+            if (first_pass) { sv = sv0; rq = rq0; }            // (wave-uniform)
+            else { sv = buf_ld_v2(r_sess, pending ? sidx * 8u : kOob); rq = buf_ld_f64(r_req, pending ? sidx * 8u : kOob); }
             const int s_dep = (int)(short)(sv.x >> 16);
             const int s_est = (int)(short)(sv.y & 0xffffu);
             const unsigned s_st = (sv.y >> 16) & 63u;
@@ -546,7 +584,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                 next_arrival = kNoArrival;
             }
             const bool more_ev = pending && cursor < n_sessions;
-            const unsigned nx = buf_ld_u32(r_sess, more_ev ? (sidx + 1u) * 8u : kOob);
+            const unsigned nx = first_pass ? nx0 : buf_ld_u32(r_sess, more_ev ? (sidx + 1u) * 8u : kOob);
+            first_pass = false;
             if (more_ev) next_arrival = (int)(short)(nx & 0xffffu);
             pending = more_ev && next_arrival <= t1;
         }
