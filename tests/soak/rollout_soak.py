@@ -1,6 +1,6 @@
 # Fused rollout kernel (greedy / random device policies, warm-started projections under greedy) against the oracle's episode
 # loop on device-generated GMM days, several seeds: counts instead of asserting.
-#   python tests/soak/rollout_soak.py [site] [N] [seeds]
+#   python tests/soak/rollout_soak.py [site] [N] [seeds] [period]
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -13,7 +13,7 @@ from sustaingym_amd.synthetic import synthetic_moer
 site = sys.argv[1] if len(sys.argv) > 1 else 'caltech'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-period = 'Summer 2019' if site == 'caltech' else 'Summer 2021'
+period = sys.argv[4] if len(sys.argv) > 4 else ('Summer 2019' if site == 'caltech' else 'Summer 2021')
 net = site_str_to_site(site); n = net.num_stations
 tabs = gmm_device_tables(site, period)
 moer = synthetic_moer(tabs['num_days'], seed=3)
