@@ -524,7 +524,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         const double gap_us = std::chrono::duration<double, std::micro>(now - e->last_split_issue).count();
         e->last_split_issue = now;
         static const double gap_limit = getenv("EVC_PIPE_GAP_US") ? atof(getenv("EVC_PIPE_GAP_US")) : 200.0;
-        const bool cold = !e->halves_pending || (phase_on && gap_us > gap_limit);
+        const bool cold = !e->halves_pending || ((phase_on || skew_us > 0) && gap_us > gap_limit);
         const bool phased = cold && phase_on && !e->timing && mid >= 64;
         if (cold) { e->prev_train_len = e->train_len; e->train_len = 0; }
         e->train_len++;
