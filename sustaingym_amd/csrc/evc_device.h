@@ -334,6 +334,24 @@ __device__ __forceinline__ double tie_snap(double y, double h) {
 // only ones for which an interior-point answer of the reference's accuracy (~1e-8 relative) could round to the
 // other pilot.  Counted by the slow path and by the streaming kernels WITH per-station debug outputs; the lean
 // streaming kernels pass no counters (the counting code alone cost them 1 us per step, measured).
+// 1 / x and 1 / sqrt(x) for the Newton iterations of the projection solvers (evc_solver.h wave_cone, evc_rowcone.h quad_cone):
+// v_rcp_f64 / v_rsq_f64 (~2^-26 relative) + two Newton steps, a few ulp — an IEEE divide is a dozen dependent instructions, a
+// sqrt + divide two dozen, and a lone wavefront pays ~7 cycles for each (profiles/r4_prim_probe.txt: divide 75, sqrt 115,
+// rcp + 2 Newton 50 cycles).  Only inside iterations whose fixed point does not depend on the last bits of a step.
+__device__ __forceinline__ double newton_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double newton_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    return r;
+}
+
 constexpr int kTieSlots = 256;
 __device__ __forceinline__ double tie_snap_counted(double y, double h, bool is_cc, unsigned long long* counters) {
 #ifdef EVC_ABL_NO_TIE_COUNT       /* ablation builds only: cost of the counting */

@@ -150,7 +150,7 @@ __device__ __forceinline__ bool quad_cone(const LdsNet& net, unsigned row, bool 
         bool conv = true;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const double inz = 1.0 / sqrt(z[2 * r] * z[2 * r] + z[2 * r + 1] * z[2 * r + 1]);
+            const double inz = newton_rsqrt(z[2 * r] * z[2 * r] + z[2 * r + 1] * z[2 * r + 1]);
             zh[2 * r] = z[2 * r] * inz;
             zh[2 * r + 1] = z[2 * r + 1] * inz;
             g[2 * r] = w[2 * r] - rmag[r] * zh[2 * r];
@@ -189,7 +189,7 @@ __device__ __forceinline__ bool quad_cone(const LdsNet& net, unsigned row, bool 
 #pragma unroll
         for (int a = 0; a < D; a++) {
             good = good && B[a][a] > 0.0;
-            inv[a] = 1.0 / B[a][a];
+            inv[a] = newton_rcp(B[a][a]);
 #pragma unroll
             for (int e = a + 1; e < D; e++) {
                 const double f = B[e][a] * inv[a];
