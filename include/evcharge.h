@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 5
+#define EVC_ABI_VERSION 6
 
 #define EVC_MAX_STATIONS     64   /* one gfx950 wavefront per environment            */
 #define EVC_MAX_CONSTRAINTS  32   /* rows of ChargingNetwork.constraint_matrix       */
@@ -329,6 +329,13 @@ int evc_clear_status(evc_engine* e);
  * iterative slow path always and by the in-row water-filling only on steps with pilots / rates / projected
  * outputs requested (the counting costs the lean streaming kernel 1 us per step). */
 int evc_read_metrics(evc_engine* e, double* out_host);
+
+/* Grid of the tie snap: values a projection solver moved are rounded to the nearest point of a
+ * 2^-log2_steps_per_amp A grid (offset by sqrt(2)-1 steps) before env.py:373-378's rounding rule.  Default 16.
+ * 8 <= log2_steps_per_amp <= 44; at 40 the grid is 2^-40 A ~ 1e-12 A, i.e. the solver's own output to its last
+ * bits — how tests/test_gpu_kkt_certificate.py reads the un-snapped optimum of env.py:178-198 out of the product
+ * kernels.  Takes effect from the next step; stream-ordered like every other call. */
+int evc_set_tie_grid(evc_engine* e, int32_t log2_steps_per_amp);
 
 /* Number of environments the most recent evc_step handed to the iterative/exact projection kernel
  * (diagnostic; synchronises the stream). */

@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SUSTAINGYM_AMD_LIB', os.path.join(_PKG, 'libevcharge_hip.so'))
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'evcharge.h')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_STATIONS, MAX_CONSTRAINTS, MAX_GROUPS, MAX_SESSIONS = 64, 32, 16, 256
 MOER_ROWS, MOER_COLS, EPISODE_STEPS = 289, 37, 288
 
@@ -98,6 +98,7 @@ SIGNATURES = {
     'evc_set_breakdown': (_i32, [_vp, _vp]),
     'evc_clear_status': (_i32, [_vp]),
     'evc_read_metrics': (_i32, [_vp, _vp]),
+    'evc_set_tie_grid': (_i32, [_vp, _i32]),
     'evc_last_slow_count': (_i32, [_vp, C.POINTER(_i32)]),
     'evc_enable_timing': (_i32, [_vp, _i32]),
     'evc_last_step_ms': (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

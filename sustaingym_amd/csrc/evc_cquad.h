@@ -403,9 +403,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                     for (int g = 0; g < P.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
 #ifdef EVC_TRACE_FILL
-                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr, nullptr, env == (unsigned)(EVC_TRACE_FILL) && t == (EVC_TRACE_FILL_T));
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr, P.tie_log2, nullptr, env == (unsigned)(EVC_TRACE_FILL) && t == (EVC_TRACE_FILL_T));
 #else
-                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr);
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, slot_cc, DBG ? P.tie_counters : nullptr, P.tie_log2);
 #endif
                     }
 #ifdef EVC_ABL_NO_REVERIFY          /* ablation builds only (WRONG results): no second evaluation of the rows, a filled environment is never queued */

@@ -34,7 +34,7 @@ struct Consts {
     static constexpr double PROJ_TOL = 1e-10;              // rows within (1+tol) r count as satisfied
     static constexpr double PROJ_TOL_KKT = 1e-12;          // dual-gradient residual target of the solver
     static constexpr double PROJ_TOL_ACCEPT = 1e-9;        // accepted if the iteration budget runs out
-    static constexpr double TIE_SNAP = 65536.0;            // solver outputs snapped to a 2^-16 A grid
+    static constexpr int TIE_LOG2 = 16;                    // solver outputs snapped to a 2^-16 A grid (default of Params::tie_log2)
     static constexpr double TIE_OFFSET = 0.41421356237309515;  // grid offset (in grid steps), sqrt(2)-1
 };
 
@@ -104,6 +104,8 @@ struct Params {
     // non-negative inner product): lowering values then never breaks a row that held before — an environment whose
     // screen left only simple rows open is settled by capping those classes, without evaluating the other rows
     int monotone_rows;
+    int tie_log2;                                   // tie-snap grid: 2^-tie_log2 A (16; evc_set_tie_grid)
+    double snap_load;                               // host side: worst sum_g |A_cg| n_g / magnitude_c (what one amp of snap per station adds to a row, relative)
     double snap_tol;                                // row tolerance after the tie snap: PROJ_TOL + what snapping can add to a row / cap
     unsigned long long* tie_counters;               // [kTieSlots][2] tie_snap_counted (64-bit: a long soak moves > 2^31 values)
     double prox_step;                               // 1 / (Gershgorin bound on lambda_max(B B')): step of the solver's proximal-gradient safeguard
@@ -324,8 +326,10 @@ struct Philox {
 
 // Tie snap of a solver-moved value: nearest point of the offset 2^-16 A grid,
 // kept inside [0, h].
-__device__ __forceinline__ double tie_snap(double y, double h) {
-    const double s = (rint(y * Consts::TIE_SNAP - Consts::TIE_OFFSET) + Consts::TIE_OFFSET) / Consts::TIE_SNAP;
+// `k` = Params::tie_log2 (16: the 2^-16 A grid; evc_set_tie_grid moves it, e.g. to 2^-40 A for the KKT certificate of the
+// un-snapped solver output, tests/test_gpu_kkt_certificate.py).  ldexp by k = the multiply by 2^k, exactly (v_ldexp_f64).
+__device__ __forceinline__ double tie_snap(double y, double h, int k) {
+    const double s = ldexp(rint(ldexp(y, k) - Consts::TIE_OFFSET) + Consts::TIE_OFFSET, -k);
     return fmin(fmax(s, 0.0), h);
 }
 
@@ -353,7 +357,7 @@ __device__ __forceinline__ double newton_rsqrt(double x) {
 }
 
 constexpr int kTieSlots = 256;
-__device__ __forceinline__ double tie_snap_counted(double y, double h, bool is_cc, unsigned long long* counters) {
+__device__ __forceinline__ double tie_snap_counted(double y, double h, bool is_cc, unsigned long long* counters, int k) {
 #ifdef EVC_ABL_NO_TIE_COUNT       /* ablation builds only: cost of the counting */
     counters = nullptr;
 #endif
@@ -379,7 +383,7 @@ __device__ __forceinline__ double tie_snap_counted(double y, double h, bool is_c
             if (nears) atomicAdd(slot + 1, (unsigned long long)__popcll(nears));
         }
     }
-    return tie_snap(y, h);
+    return tie_snap(y, h, k);
 }
 
 // env.py:366-378: normalised action -> EVSE-legal pilot (A).  y = 32 * action (float64).

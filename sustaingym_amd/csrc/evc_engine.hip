@@ -296,9 +296,11 @@ int build_tables(const evc_network_desc* net, Params& P, NetTables& T) {
             double load = 0.0;
             for (int g = 0; g < P.G; g++)
                 load += std::fabs(net->constraint_matrix[c * n + rep[g]]) * __builtin_popcountll(P.group_mask[g]);
-            worst = std::max(worst, load * (1.0 / 131072.0) / net->magnitudes[c]);
+            worst = std::max(worst, load / net->magnitudes[c]);
         }
-        P.snap_tol = Consts::PROJ_TOL + worst;
+        P.snap_load = worst;                                   // amps-of-row per amp-of-station over the limit, worst row
+        P.tie_log2 = Consts::TIE_LOG2;
+        P.snap_tol = Consts::PROJ_TOL + worst * std::ldexp(1.0, -(P.tie_log2 + 1));
     }
     // simple rows: all non-zero coefficients inside one station class -> a cap on that class sum
     P.simple_rows = 0u;
@@ -1465,6 +1467,16 @@ int evc_read_metrics(evc_engine* e, double* out_host) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(copy_d2h(out_host, e->d_metrics, sizeof(double) * 8, e->stream));
     out_host[3] = (double)e->env_steps;
+    return EVC_OK;
+}
+
+int evc_set_tie_grid(evc_engine* e, int32_t log2_steps_per_amp) {
+    if (!e) return fail(EVC_EINVAL, "null engine");
+    if (log2_steps_per_amp < 8 || log2_steps_per_amp > 44)
+        return fail(EVC_EINVAL, "tie grid 2^-%d A outside 2^-8 .. 2^-44 A", log2_steps_per_amp);
+    if (int rc = bind(e)) return rc;
+    e->P.tie_log2 = log2_steps_per_amp;
+    e->P.snap_tol = Consts::PROJ_TOL + e->P.snap_load * std::ldexp(1.0, -(log2_steps_per_amp + 1));
     return EVC_OK;
 }
 

@@ -51,7 +51,7 @@ struct LdsRare {
     double class_cap[EVC_MAX_GROUPS];
     double snap_tol;
     unsigned simple_rows, cap_classes;
-    int monotone_rows, G;
+    int monotone_rows, G, tie_log2;
 };
 __device__ __forceinline__ void stage_rare(LdsRare& r, const Params& P) {          // before a workgroup barrier
     // one lane, uniform indices: the fields arrive through the scalar loads the kernel's other arguments take anyway (a
@@ -60,7 +60,7 @@ __device__ __forceinline__ void stage_rare(LdsRare& r, const Params& P) {       
 #pragma unroll
         for (int g = 0; g < EVC_MAX_GROUPS; g++) r.class_cap[g] = P.class_cap[g];
         r.snap_tol = P.snap_tol; r.simple_rows = P.simple_rows; r.cap_classes = P.cap_classes;
-        r.monotone_rows = P.monotone_rows; r.G = P.G;
+        r.monotone_rows = P.monotone_rows; r.G = P.G; r.tie_log2 = P.tie_log2;
     }
 }
 
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void step_kernel(Params P, StepIO io) {
                         unsigned cv2;
                         if (exact_rows(P, net, ln, lane, yw, cv2) == 0ull) {
                             // tie snap of solver-moved values
-                            if (yw != y) yw = tie_snap_counted(yw, h, ln.is_cc, P.tie_counters);
+                            if (yw != y) yw = tie_snap_counted(yw, h, ln.is_cc, P.tie_counters, P.tie_log2);
                             y = yw;
                             solved = true;
                         }

@@ -143,7 +143,7 @@ __device__ __forceinline__ bool quad_exact_rows(int G, const double* class_cap, 
 __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gid)[kSlots],
                                                const float (&act)[kSlots], const int (&dep)[kSlots],
                                                const double (&rem)[kSlots], double cap,
-                                               double (&y)[kSlots], const bool (&is_cc)[kSlots], unsigned long long* counters,
+                                               double (&y)[kSlots], const bool (&is_cc)[kSlots], unsigned long long* counters, int tie_log2,
                                                unsigned long long* pass_count = nullptr, bool trace = false) {
     // target b and cap h of every slot, once (slots that are compile-time empty fold away)
     double b[kSlots], h[kSlots];
@@ -241,7 +241,7 @@ __device__ __forceinline__ void quad_waterfill(bool on, int g, const int (&st_gi
         if (on && in_g[j]) {
             const double yw = fmin(fmax(b[j] - nu, 0.0), h[j]);
             // tie snap of solver-moved values
-            y[j] = (yw != fmin(b[j], h[j])) ? tie_snap_counted(yw, h[j], is_cc[j], counters) : yw;
+            y[j] = (yw != fmin(b[j], h[j])) ? tie_snap_counted(yw, h[j], is_cc[j], counters, tie_log2) : yw;
         }
     }
 }
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, EVC_QUAD_WAVES) void step_kernel_quad(Params P
                     // slow kernel recomputes them from the stored state
                     for (int g = 0; g < P.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
-                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, st_cc, DBG ? P.tie_counters : nullptr);
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, P.class_cap[g], y, st_cc, DBG ? P.tie_counters : nullptr, P.tie_log2);
                     }
                     unsigned cv2;
                     // re-verify every row on the snapped values: Params::snap_tol = PROJ_TOL + the most the snap can add to a row

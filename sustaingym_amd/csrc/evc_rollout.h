@@ -95,7 +95,7 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
         const bool warm_on = tag != 0u && P.m <= 16;
         const bool warm_ok = warm_on && tag > 1u && S.warm_tag[w][row] == (int)tag - 1;
         bool stored = false;
-        const bool settled = quad_project(S.rare.G, S.rare.class_cap, S.rare.simple_rows, P.tie_counters, S.net, q, (unsigned)P.m, row, on, st_gid, is_cc, b, h, y,
+        const bool settled = quad_project(S.rare.G, S.rare.class_cap, S.rare.simple_rows, P.tie_counters, S.rare.tie_log2, S.net, q, (unsigned)P.m, row, on, st_gid, is_cc, b, h, y,
                                           warm_on ? S.zwarm[w][row] : nullptr, warm_ok, &stored);
         if (warm_on && on && settled && q == 0u) S.warm_tag[w][row] = stored ? (int)tag : 0;
         if (settled) {
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                     for (int c = 0; c < kSlots; c++) slot_cc[c] = valid[c] && (st_info[st[c]] >> 7) != 0u;
                     for (int g = 0; g < S.rare.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
-                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, S.rare.class_cap[g], y, slot_cc, nullptr);
+                        if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, S.rare.class_cap[g], y, slot_cc, nullptr, S.rare.tie_log2);
                     }
 #if defined(EVC_RABL) && EVC_RABL == 3   /* ablation (WRONG results): exact rows + filling, no second evaluation, no solve */
                     anyviol = false;

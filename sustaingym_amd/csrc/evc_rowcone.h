@@ -272,7 +272,7 @@ __device__ __forceinline__ void quad_waterfill_bh(bool on, int g, const int (&st
 // filling, no chain; a row the warm solve does not settle is left to the general path.  Whatever settles a row with at most
 // two active rows (a filled cap counts: its multiplier is nu cf / |cf|^2 on its simple row) leaves its multipliers in zw and
 // returns stored = true; zw may be null.
-__device__ __forceinline__ bool quad_project(int G, const double* class_cap, unsigned simple_rows, unsigned long long* tie_counters, const LdsNet& net,
+__device__ __forceinline__ bool quad_project(int G, const double* class_cap, unsigned simple_rows, unsigned long long* tie_counters, int tie_log2, const LdsNet& net,
                                              unsigned q, unsigned m, unsigned row, bool on, const int (&st_gid)[kSlots],
                                              const bool (&is_cc)[kSlots], const double (&b)[kSlots], const double (&h)[kSlots],
                                              double (&y)[kSlots], double (*zw)[2] = nullptr, bool warm_ok = false, bool* stored = nullptr) {
@@ -433,7 +433,7 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
     if (__ballot(settled) != 0ull) {
 #pragma unroll
         for (int j = 0; j < kSlots; j++)
-            if (settled && st_gid[j] >= 0 && y[j] != y0[j]) y[j] = tie_snap_counted(y[j], h[j], is_cc[j], tie_counters);
+            if (settled && st_gid[j] >= 0 && y[j] != y0[j]) y[j] = tie_snap_counted(y[j], h[j], is_cc[j], tie_counters, tie_log2);
     }
     return settled;
 }

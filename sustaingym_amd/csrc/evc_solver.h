@@ -855,7 +855,7 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
     // Tie snap: values the solver moved are snapped to a 2^-16 A grid so that
     // optima sitting exactly on a rounding boundary of env.py:373-378 round deterministically.
     double y = ln.y;
-    if (y != fmin(ln.b, ln.h)) y = tie_snap_counted(y, ln.h, lnet.is_cc, P.tie_counters);
+    if (y != fmin(ln.b, ln.h)) y = tie_snap_counted(y, ln.h, lnet.is_cc, P.tie_counters, P.tie_log2);
     return y;
 }
 

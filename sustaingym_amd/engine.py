@@ -462,6 +462,11 @@ class StepEngine:
                 'env_steps': out[3], 'episodes_finished': out[4], 'envs_with_status': out[5],
                 'solver_moved_values': out[6], 'tie_snap_near_boundary': out[7]}
 
+    def set_tie_grid(self, log2_steps_per_amp: int = 16) -> None:
+        """Grid of the tie snap, 2^-k A (``evc_set_tie_grid``; default 16).  k = 40 hands out the solvers'
+        un-snapped optimum (the KKT certificate test)."""
+        check(self.lib.evc_set_tie_grid(self.handle, int(log2_steps_per_amp)), 'evc_set_tie_grid')
+
     def last_slow_count(self) -> int:
         c = C.c_int32()
         check(self.lib.evc_last_slow_count(self.handle, C.byref(c)), 'evc_last_slow_count')

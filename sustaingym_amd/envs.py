@@ -612,16 +612,18 @@ class EVChargingVectorEnv(_VectorEnvBase):
                     self._lean_views = (self._wrap_obs(so['obs']), so['reward'], so['terminated'].view(torch.bool),
                                         {'profit': bd[:, 0], 'carbon_cost': bd[:, 1], 'excess_charge': bd[:, 2]})
                     self._lean_info = None
-                assert actions.shape[0] == N and actions.shape[1] == self.num_stations
+                assert actions.dim() == 2 and actions.shape[0] == N and actions.shape[1] == self.num_stations
                 self._stepper(actions.data_ptr())
                 out = self._stepper_out
                 if not boundary:
                     obs_v, rew_v, term_v, bd_v = self._lean_views
                     if self._false_dev is None:
                         self._false_dev = term_v.new_zeros(N)
-                    if self._lean_info is None or self._info_max_profit is None:
-                        if self._info_max_profit is None:
-                            self._info_max_profit = self._max_profit[self._cur_slot]
+                    if self._info_max_profit is None:            # first step of an episode (reset() / the boundary step cleared it)
+                        self._info_max_profit = self._max_profit[self._cur_slot]
+                    if self._lean_info is None or self._lean_info['max_profit'] is not self._info_max_profit:
+                        # one dict per EPISODE: rebuilt whenever the episode's max_profit array was (the boundary step and
+                        # reset() refill _info_max_profit through _infos(), so testing it for None here is not enough)
                         self._lean_info = {'max_profit': self._info_max_profit, 'reward_breakdown': bd_v}
                     return obs_v, rew_v, term_v, self._false_dev, self._lean_info
             else:
