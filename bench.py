@@ -89,6 +89,8 @@ def parse_args(argv=None):
                    help='testing aid: every rank uses cuda:0 (needs --backend gloo)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-secondary', action='store_true', help='skip the secondary records (GMM days, multi-agent, battery)')
+    p.add_argument('--leg-budget-s', type=float, default=60.0, help='time box of one secondary record')
+    p.add_argument('--secondary-budget-s', type=float, default=240.0, help='time box of all secondary records together')
     p.add_argument('--cpu-envs', type=int, default=8192)
     p.add_argument('--cpu-steps', type=int, default=96, help='minimum timed steps of the cpu_baseline sample')
     p.add_argument('--kernel-timing-steps', type=int, default=288,
@@ -926,6 +928,39 @@ def secondary_battery_rollout(dev_index, N=16384, T=EPISODE) -> dict:
     return out
 
 
+class LegTimeout(Exception):
+    pass
+
+
+def run_leg(fn, budget_s: float, deadline: float):
+    """One secondary record, time-boxed: SIGALRM after `budget_s` seconds (or at the overall deadline of the
+    secondary section, whichever is sooner) raises inside the leg's Python loop; a leg that fails, overruns or is skipped
+    leaves an `error` record and never costs the headline line.  (A kernel that never returns would still block inside the
+    HIP call: the alarm bounds host loops and waits the interpreter returns from, which is every wait bench.py has.)"""
+    import signal
+    left = deadline - time.monotonic()
+    if left <= 1.0:
+        return {'error': 'skipped: the secondary section used up --secondary-budget-s'}
+
+    def on_alarm(signum, frame):
+        raise LegTimeout()
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    t0 = time.monotonic()
+    signal.setitimer(signal.ITIMER_REAL, min(budget_s, left))
+    try:
+        rec = fn()
+        if isinstance(rec, dict):
+            rec['leg_seconds'] = round(time.monotonic() - t0, 2)
+        return rec
+    except LegTimeout:
+        return {'error': f'timed out after {time.monotonic() - t0:.1f} s (--leg-budget-s {budget_s})'}
+    except Exception as exc:          # a secondary record must never cost the headline
+        return {'error': f'{type(exc).__name__}: {exc}'}
+    finally:
+        signal.setitimer(signal.ITIMER_REAL, 0)
+        signal.signal(signal.SIGALRM, old)
+
+
 def main():
     args = parse_args()
     if args.dry_rccl:
@@ -1022,6 +1057,12 @@ def main():
         timed = w.time_kernels(args.kernel_timing_steps)
         roofline = roofline_record(w, timed, algorithmic_bytes_per_env_step(n, k))
         roofline['launch_overhead_ms'] = round(elapsed / args.steps * 1e3 - roofline.get('step_period_ms', roofline['avg_kernel_ms']), 5)
+        # the same accounting on the window the driver's clock brackets (`ms_per_step`): `frac` above comes from separate
+        # windows measured after it (steady trains, HIP events); this one includes the window's cold start and final drain
+        alg_step = algorithmic_bytes_per_env_step(n, k) * N
+        roofline['frac_timed_window'] = round(alg_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)
+        if roofline.get('traffic'):
+            roofline['frac_traffic_timed_window'] = round(roofline['traffic'] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)
         if w.pipeline == 2 and not args.no_single_launch:
             # the same workload as ONE launch per step (evc_set_pipeline(1)), for continuity with rounds 1-2
             w.eng.set_pipeline(1)
@@ -1056,6 +1097,7 @@ def main():
     w.close()
     if rank == 0 and world == 1 and not args.no_secondary:
         secondary = {}
+        legs_deadline = time.monotonic() + args.secondary_budget_s
         for name, fn in (('sync_reference', lambda: secondary_sync_reference(args.site, local_rank, args.battery, project)),
                          ('gmm_caltech', lambda: secondary_days('caltech', 'gmm', local_rank, args.battery)),
                          ('gmm_jpl', lambda: secondary_days('jpl', 'gmm', local_rank, args.battery)),
@@ -1072,10 +1114,7 @@ def main():
                          ('battery_16384', lambda: secondary_battery(local_rank)),
                          ('battery_rollout_16384', lambda: secondary_battery_rollout(local_rank)),
                          ('tie_snap_reach', lambda: secondary_tie_snap(local_rank, args.battery))):
-            try:
-                secondary[name] = fn()
-            except Exception as exc:          # a secondary record must never cost the headline
-                secondary[name] = {'error': f'{type(exc).__name__}: {exc}'}
+            secondary[name] = run_leg(fn, args.leg_budget_s, legs_deadline)
 
     # The CPU baseline runs LAST: its OpenMP threads saturate the container's CPU quota and the cgroup throttles the whole
     # process for a while afterwards — measured GPU legs that follow it become host-bound (secondary records 20 % off).
@@ -1111,6 +1150,14 @@ def main():
             'strong_scaling': strong,
             # the reference's own episode distribution beside the headline's quiet synthetic days (secondary.gmm_caltech)
             'value_reference_distribution': (secondary or {}).get('gmm_caltech', {}).get('env_steps_per_s') if secondary else None,
+            # ... its step time, its congested 4-hour blocks (one launch per step) and the JPL day, up here where a truncated tail still shows them
+            'gmm_days': None if not secondary else {
+                key: {'us_per_step': round(rec['ms_per_step'] * 1e3, 2), 'single_launch_us': round(rec['single_launch']['ms_per_step'] * 1e3, 2),
+                      'kernel_us_by_4h': rec['kernel_us_by_4h'], 'solver_kernel_us_by_4h': rec['solver_kernel_us_by_4h']}
+                for key, rec in ((k2, secondary.get(k2) or {}) for k2 in ('gmm_caltech', 'gmm_jpl')) if 'ms_per_step' in rec},
+            'rollout_greedy_gmm': None if not secondary else {
+                key: {'env_steps_per_s': rec['env_steps_per_s'], 'us_per_period': rec['us_per_period']}
+                for key, rec in ((k2, secondary.get(k2) or {}) for k2 in ('rollout_greedy_65536_gmm', 'rollout_greedy_65536_jpl_gmm')) if 'us_per_period' in rec},
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'episode_generation': episode_generation,
             'episode_metrics': {'profit': float(total[0]), 'carbon_cost': float(total[1]),
                                 'excess_charge': float(total[2]), 'episodes_finished': float(total[4]),

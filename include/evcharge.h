@@ -171,6 +171,8 @@ int evc_join(evc_engine* e);
  * [env_lo, env_hi) of the previous step's outputs, writes the same rows of the action buffer — is ordered after the
  * half's previous launch and before its next one by the stream itself, so the policy of one half runs under the other
  * half's step and no join is needed between steps.  Rows of the other half must not be touched from this stream.
+ * A step the engine does not split (small batches, staged action kinds, debug outputs: one launch on the engine's stream)
+ * keeps the same contract once this function has been called: it waits for both side streams and both wait for it.
  * Valid after evc_set_pipeline(e, 2); the streams live as long as the engine. */
 int evc_pipeline_half(evc_engine* e, int32_t half, void** hip_stream, int32_t* env_lo, int32_t* env_hi);
 /* How many steps of this engine ran as two half launches so far, and (ordered, may be NULL) how many of those found

@@ -127,6 +127,7 @@ struct evc_engine {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr}, phase_ev = nullptr;
     bool halves_pending = false, side_warmed = false, last_split = false, side_ready = false;
+    bool halves_exposed = false;  // evc_pipeline_half handed the side streams to the caller (closed loop per half)
     unsigned train_len = 0, prev_train_len = 0;   // pipelined steps since the last join, and in the train before it
     std::chrono::steady_clock::time_point last_split_issue{};   // host time of the last pipelined step's issue
     unsigned long long split_steps = 0;   // steps that ran as two half launches (evc_pipelined_steps) ...
@@ -491,6 +492,16 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     if (!split && e->h_qlen) ((volatile int*)e->h_qlen)[kQlenRing + (e->step_index % kQlenRing)] = 0;
     if (!split)
         if (int rc = join_halves(e)) return rc;
+    // A caller that enqueues per-half work on the side streams (evc_pipeline_half) relies on "after this half's previous
+    // launch, before its next one".  A step that is NOT split (small batches, a staged action kind, debug outputs) is one
+    // launch on the engine's stream: it is ordered after whatever the caller put on both side streams, and both side streams
+    // are ordered after it below — the same contract, without the overlap (it raced on the action buffer).
+    const bool guard_unsplit = e->pipeline == 2 && !split && e->halves_exposed;
+    if (guard_unsplit)
+        for (int h = 0; h < 2; h++) {
+            HIP_TRY(hipEventRecord(e->join_ev[h], e->side[h]));
+            HIP_TRY(hipStreamWaitEvent(e->stream, e->join_ev[h], 0));
+        }
     auto launch_split = [&](auto kernel, auto slow_kernel, bool with_slow) {
         // Both halves wait for whatever the engine's stream still holds (the caller's actions): one event, recorded there and
         // waited for by both side streams — but only if the stream holds anything.  An idle stream (actions staged earlier,
@@ -677,6 +688,10 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         e->ev_valid = true;
         e->ev_slow = solver_ran;
         e->ev_split = split;
+    }
+    if (guard_unsplit) {
+        HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
+        for (int h = 0; h < 2; h++) HIP_TRY(hipStreamWaitEvent(e->side[h], e->fork_ev, 0));
     }
     HIP_TRY(hipGetLastError());
     e->env_steps += (unsigned long long)e->P.N;
@@ -994,6 +1009,7 @@ int evc_pipeline_half(evc_engine* e, int32_t half, void** hip_stream, int32_t* e
     if (half != 0 && half != 1) return fail(EVC_EINVAL, "evc_pipeline_half: half must be 0 or 1, got %d", half);
     if (!e->side_ready) return fail(EVC_ESTATE, "evc_pipeline_half: call evc_set_pipeline(e, 2) first");
     const int nq = (e->P.N + 3) / 4, mid = (nq / 2) & ~7;      // the split of launch_split
+    e->halves_exposed = true;
     *hip_stream = (void*)e->side[half];
     *env_lo = half ? mid * 4 : 0;
     *env_hi = half ? e->P.N : mid * 4;

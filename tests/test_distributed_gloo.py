@@ -72,6 +72,53 @@ def test_two_gloo_ranks_match_single_process():
     assert np.array_equal(tot, expect) and pr.shape == (1, 6)
 
 
+# ---- more than two ranks, a batch that does not divide (the first 8-rank run is the driver's: make it boring) ----
+
+def _cover_worker(rank, world, port, global_envs, q):
+    from sustaingym_amd.distributed import all_gather_vector
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lo, hi = shard_range(global_envs, rank, world)
+    seeds = np.asarray(shard_seeds(1000, rank, world, global_envs), dtype=np.float64)
+    ids = np.arange(lo, hi, dtype=np.float64)
+    local = np.array([lo, hi, ids.sum(), (ids * ids).sum(), seeds.sum(), len(seeds), rank])
+    rows = all_gather_vector(local)
+    tmax = max_over_ranks(float(10 * rank))
+    dist.barrier()
+    if rank == 0:
+        q.put((rows, tmax))
+    dist.destroy_process_group()
+
+
+def test_eight_gloo_ranks_cover_a_batch_that_does_not_divide():
+    global_envs, world = 65537, 8
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cover_worker, args=(r, world, port, global_envs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    rows, tmax = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert rows.shape == (8, 7) and list(rows[:, 6]) == list(range(8)) and tmax == 70.0     # gathered in rank order
+    assert rows[0, 0] == 0 and rows[-1, 1] == global_envs
+    assert np.array_equal(rows[1:, 0], rows[:-1, 1])                                         # contiguous, no gap, no overlap
+    sizes = rows[:, 1] - rows[:, 0]
+    assert sizes.max() - sizes.min() <= 1 and sizes.sum() == global_envs
+    ids = np.arange(global_envs, dtype=np.float64)
+    assert rows[:, 2].sum() == ids.sum() and rows[:, 3].sum() == (ids * ids).sum()           # every id exactly once
+    assert rows[:, 4].sum() == (ids + 1000).sum() and rows[:, 5].sum() == global_envs        # seed of env i = base + i
+    # seeds do not depend on the number of ranks the job runs on
+    for w in (1, 2, 3, 8):
+        flat = [s for r in range(w) for s in shard_seeds(1000, r, w, 1001)]
+        assert flat == [1000 + i for i in range(1001)]
+
+
 # ---- BASELINE config 4: battery-dispatch environments sharded over the ranks ---------------------
 
 def _battery_shard_returns(lo, hi, steps=40):

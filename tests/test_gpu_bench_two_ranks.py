@@ -39,3 +39,24 @@ def test_bench_two_ranks_on_one_device():
     assert rec['roofline'] and rec['roofline']['bound'] == 'hbm'
     # the metrics gathered over the process group are both ranks' (episodes finish in both shards)
     assert rec['episode_metrics']['episodes_finished'] > 0
+
+
+def test_bench_eight_ranks_on_one_device():
+    """The driver's 8-rank launch shape (VERDICT r4 "next" #8): eight self-spawned ranks, gloo, one device, 4 096 environments
+    each — every rank reports, the shards add up, the record says 8."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    steps, warmup, n = 20, 5, 4096
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--single-device',
+                        '--envs-per-gpu', str(n), '--steps', str(steps), '--warmup', str(warmup), '--no-secondary',
+                        '--no-cpu-baseline', '--bank', '1024'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 8 and rec['ranks_seen'] == 8 and rec['scaling'] == 'weak'
+    assert rec['per_rank']['env_steps_timed'] == [n * steps] * 8 and rec['env_steps_timed'] == 8 * n * steps
+    assert rec['config']['global_envs'] == 8 * n and rec['config']['envs_per_gpu'] == n
+    assert abs(rec['value'] - 8 * n * steps / (rec['ms_per_step'] * 1e-3 * steps)) <= 1e-3 * rec['value']

@@ -538,3 +538,30 @@ def test_integration_md_binding_stub_runs():
         assert r == r2 and term == done2
     assert term
     env.close()
+
+
+@pytest.mark.gpu
+def test_torch_lean_path_info_max_profit_follows_the_episode():
+    """the lean torch path caches its info dict; after an episode boundary (and after reset) it must hand out the
+    NEW episode's max_profit, not the cached array of the previous one (env.py:403-406, 422-429)."""
+    import torch
+    from sustaingym_amd.event_generation import DeviceGMMTraceGenerator
+    N = 256
+    venv = EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2019', seed=9), num_envs=N, output='torch')
+    venv.reset(seed=9)
+    act = torch.full((N, venv.num_stations), 0.5, dtype=torch.float32, device='cuda')
+    first = None
+    for t in range(1, 292):
+        _, _, _, _, info = venv.step(act)
+        expect = venv._max_profit[venv._cur_slot]
+        if t == 1:
+            first = np.array(info['max_profit'])
+        if t != 288:                                              # the boundary step's own info reports the NEXT episode's (gymnasium autoreset)
+            assert np.array_equal(np.asarray(info['max_profit']), expect), t
+        if t == 289:
+            assert not np.array_equal(np.asarray(info['max_profit']), first)      # a different episode's values
+            assert 'final_observation' not in info
+    venv.reset(seed=123)
+    _, _, _, _, info = venv.step(act)
+    assert np.array_equal(np.asarray(info['max_profit']), venv._max_profit[venv._cur_slot])
+    venv.close()

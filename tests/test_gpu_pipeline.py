@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 N = 32768          # the smallest batches the engine splits: a half must still give every wavefront of the grid 4 quads
 
 
-def _engine(net, wl, project, pipeline):
+def _engine(net, wl, project, pipeline, N=N):
     from sustaingym_amd.engine import StepEngine
     P = len(wl['n_sessions'])
     eng = StepEngine(net, N, project_action=project, autoreset=True, bank_slots=P, max_sessions=wl['sessions'].shape[1],
@@ -233,5 +233,46 @@ def test_closed_loop_with_per_half_policies_equals_the_single_launch(monkeypatch
         assert torch.equal(o1[k], o2[k]), k
     assert torch.equal(a1, a2)
     _assert_same(_state(one), _state(two), 'closed loop')
+    one.close()
+    two.close()
+
+
+def test_closed_loop_per_half_policies_on_a_batch_the_engine_does_not_split(monkeypatch):
+    """with 2 048 environments a step is ONE launch on the engine's stream although evc_set_pipeline(2) is on and
+    evc_pipeline_half hands out the side streams.  The per-half contract must still hold (policy of step k+1 after step k's
+    outputs, step k+1 after the policy): a slow policy on the side streams (a spin kernel in front of it) would otherwise
+    lose the race for the action buffer."""
+    import torch
+    from sustaingym_amd.network import caltech_acn
+    monkeypatch.setenv('EVC_DRAIN', '1')
+    n_small = 2048
+    net = caltech_acn()
+    n = net.num_stations
+    wl = make_workload(net, n_small, bank_slots=512, seed=19, busy=True, moer_days=4)
+    one, two = _engine(net, wl, True, 1, n_small), _engine(net, wl, True, 2, n_small)
+    assert np.array_equal(to_host(one.reset()), to_host(two.reset()))
+    s1, o1 = one.make_stepper()
+    s2, o2 = two.make_stepper()
+    a1 = torch.zeros((n_small, n), dtype=torch.float32, device='cuda')
+    a2 = torch.zeros((n_small, n), dtype=torch.float32, device='cuda')
+    halves = two.pipeline_halves()
+    torch.cuda.synchronize()
+    for t in range(120):
+        torch.sign(o1['obs'][:, :n], out=a1)
+        s1(a1.data_ptr())
+    torch.cuda.synchronize()
+    for t in range(120):
+        for sl, st in halves:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(200_000)                # ~0.1 ms: the step must wait for it
+                torch.sign(o2['obs'][sl, :n], out=a2[sl])
+        s2(a2.data_ptr())
+    assert two.pipelined_steps() == 0                     # never split at this size
+    two.join()
+    torch.cuda.synchronize()
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    assert torch.equal(a1, a2)
+    _assert_same(_state(one), _state(two), 'closed loop, unsplit')
     one.close()
     two.close()
