@@ -37,10 +37,6 @@ struct alignas(16) StationCell {
 // streaming work is done, the same memory serves as the slow path's SolverLds = {LdsNet net; workspace}
 // (in-kernel queue drain, DRAIN = true).
 constexpr int kDrainListMax = 256;
-constexpr int kDeferMax = 256;          // a row that finds the list full is finished where it stands, as before
-#ifndef EVC_DEFER
-#define EVC_DEFER 1
-#endif
 struct CquadLds {
     LdsNet net;
     union Images {
@@ -60,12 +56,6 @@ struct CquadLds {
     int next_quad;              // next of the workgroup's quads nobody has taken yet (see the loop over quads)
     int local_count;            // DRAIN: environments this workgroup queued for its own slow path ...
     int local_list[kDrainListMax];   // ... (the engine enables DRAIN only while a workgroup steps at most that many environments)
-    // DEFER (round 5): environments whose float32 screen left a row open are not finished where they stand — with four
-    // environments per wavefront the exact rows / water-filling ran at one or two live DPP rows in ~75 % of the wavefronts of a
-    // congested midday — but listed here, and stepped in a second pass over the list, four listed environments per wavefront.
-    int next_group;             // second pass: next group of four listed environments nobody has taken yet
-    int defer_count;
-    int defer_list[kDeferMax];
 };
 
 // The in-kernel drain behind a real call (DRAIN kernels): inlined, the slow path's code and live ranges cost
@@ -167,23 +157,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         double rem0;
         float a[kSlots];
     };
-    // lean projecting kernels: undecided environments are stepped by a second, dense pass over a list (CquadLds::defer_list)
-    constexpr bool DEFER = PROJECT && !DBG && (EVC_DEFER != 0);
-    bool second = false;                            // workgroup-uniform: the pass over the list
-    int defer_n = 0;
-    auto env_of = [&](int item) -> int {            // environment of this row in a quad (first pass) / group of the list (second), -1: none
-        if (item < 0) return -1;
-        if (DEFER && second) {
-            const int idx = item * 4 + (int)row;
-            return idx < defer_n ? S.defer_list[idx] : -1;
-        }
-        const unsigned e = (unsigned)item * 4u + row;
-        return e < N ? (int)e : -1;
-    };
-    auto issue = [&](int env_i) {
+    auto issue = [&](int quad_) {
         QuadRaw L;
-        const unsigned env_ = (unsigned)env_i;
-        const bool ev_ = env_i >= 0;
+        const unsigned env_ = (unsigned)quad_ * 4u + row;
+        const bool ev_ = quad_ >= 0 && env_ < N;
         const unsigned eb_ = env_ * n;
         const unsigned soff = ev_ ? env_ * 32u : kOob;
         L.s0 = buf_ld_v4(r_scal, soff);
@@ -200,9 +177,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     // The first quad's loads are issued before the LDS tables are built: the two latency chains (network
     // tables from global memory, first state / action rows) overlap instead of following each other —
     // a wave runs only four iterations at N = 65 536, so the prologue is a visible share of the launch.
-    QuadRaw nxt = issue(env_of(walk.first < walk.hi ? walk.first : -1));
+    QuadRaw nxt = issue(walk.first < walk.hi ? walk.first : -1);
 
-    if (tid == 0u) { S.next_quad = 4; S.next_group = 4; S.defer_count = 0; }
+    if (tid == 0u) S.next_quad = 4;
     if (DRAIN && tid == 0u) {
         S.local_count = 0;
         // the other control block still holds the PREVIOUS step's total (its launch is complete): report it to
@@ -255,19 +232,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         asm volatile("" ::: "memory");
     };
 
-    auto take_group = [&]() {
-        int k = 0;
-        if (lane == 0u) k = __hip_atomic_fetch_add(&S.next_group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        k = rfl(k);
-        return k * 4 < defer_n ? k : -1;
-    };
-    int quad = walk.first < walk.hi ? walk.first : -1;       // first pass: a quad; second pass: a group of four listed environments
-    for (;;) {
-    for (; quad >= 0;) {
+    for (int quad = walk.first < walk.hi ? walk.first : -1; quad >= 0;) {
         int quad_next = -1;                                  // set where the next quad's loads are issued
-        const int env_i = env_of(quad);
-        const unsigned env = (unsigned)env_i;
-        const bool ev = env_i >= 0;
+        const unsigned env = (unsigned)quad * 4u + row;
+        const bool ev = env < N;
         const unsigned ebase = env * n;
         const unsigned obase = env * F;                     // observation row
         const QuadRaw cur = nxt;
@@ -340,8 +308,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             nx0 = buf_ld_u32(r_sess, (pend0 && cursor + 1 < n_sessions) ? (sidx0 + 1u) * 8u : kOob);
         }
 #ifdef EVC_PREFETCH_EARLY          /* measurement builds: the next quad's rows requested at the top of the iteration */
-        quad_next = (DEFER && second) ? take_group() : take_quad();
-        if (quad_next >= 0) nxt = issue(env_of(quad_next));
+        quad_next = take_quad();
+        if (quad_next >= 0) nxt = issue(quad_next);
 #endif
         // The rest of the iteration is instantiated for NS = 1..4 entry slots per lane: the widest row of
         // the wave decides (NS = 1: every row has <= 16 entries, the normal case of a quiet network;
@@ -411,18 +379,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 #ifdef EVC_ABL_NO_EXACT            /* ablation builds only (wrong results): cost of the exact path on congested days */
             undecided = false;
 #endif
-            if (DEFER && !second && __builtin_expect(__ballot(undecided) != 0ull, 0)) {
-                // first pass: list the row instead (it writes nothing here, like a queued row) — unless the list is full
-                bool ok = false;
-                if (undecided && q == 0u) {
-                    const int at = atomicAdd(&S.defer_count, 1);
-                    ok = at < kDeferMax;
-                    if (ok) S.defer_list[at] = (int)env;
-                }
-                const bool deferred = row_any(ok, row);
-                live = live && !deferred;
-                undecided = undecided && !deferred;
-            }
             if (__builtin_expect(__ballot(undecided) != 0ull, 0)) {
                 // Rare (wave-uniform branch): exact float64 rows; class-cap (pod breaker) violations
                 // are projected in closed form inside the row; anything else goes to the slow kernel.
@@ -671,8 +627,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // the register-hungry part of the iteration: 184 -> 155 spilled VGPRs, -0.7 us per step with synchronised phases);
         // nothing to fetch after the last quad
 #ifndef EVC_PREFETCH_EARLY
-        quad_next = (DEFER && second) ? take_group() : take_quad();
-        if (quad_next >= 0) nxt = issue(env_of(quad_next));
+        quad_next = take_quad();
+        if (quad_next >= 0) nxt = issue(quad_next);
 #endif
         // ---- observation image: demands / est_departures of the surviving entries ----
         auto scatter_obs = [&](int c) {
@@ -795,14 +751,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         }
         lds_sync();
         quad = quad_next;
-    }
-    if (!DEFER || second) break;
-    __syncthreads();                           // every wavefront's listed rows are in the list
-    defer_n = rfl(S.defer_count < kDeferMax ? S.defer_count : kDeferMax);
-    if (defer_n == 0) break;
-    second = true;
-    quad = (int)wv * 4 < defer_n ? (int)wv : -1;
-    nxt = issue(env_of(quad));
     }
 
     if (DRAIN) {
