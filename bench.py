@@ -903,10 +903,17 @@ def secondary_battery_rollout(dev_index, N=16384, T=EPISODE) -> dict:
     g = torch.Generator(device=dev)
     g.manual_seed(5)
     ring = (torch.rand((R, N, 2 * k), device=dev, generator=g) * 90.0).contiguous()
-    traj = (torch.empty((T, N, 4 * k + 6), dtype=torch.float32, device=dev), torch.empty((T, N), dtype=torch.float64, device=dev))
+    F = 4 * k + 6
+    rew_traj = torch.empty((T, N), dtype=torch.float64, device=dev)
+    # the trajectory as BatteryDispatchVectorEnv.rollout allocates it by default — rows 160 floats (640 B) apart, the
+    # [T, N, 150] view handed out (bat_rollout_pitched, round 5) — and with packed 600-byte rows (round 4's form)
+    bufs = {'with_trajectory': (torch.zeros((T, N, 160), dtype=torch.float32, device=dev)[:, :, :F], rew_traj),
+            'with_trajectory_packed_rows': (torch.empty((T, N, F), dtype=torch.float32, device=dev), rew_traj),
+            'last_outputs_only': None}
     slots = np.arange(N) % 1024
     out = {}
-    for name, trajectory in (('with_trajectory', True), ('last_outputs_only', False)):
+    for name, traj in bufs.items():
+        trajectory = traj is not None
         ms = []
         for rep in range(6):
             env.reset(slots)

@@ -73,6 +73,12 @@ int bat_step(bat_engine* e, const float* bids_dev, float* obs_dev, double* rewar
  * observation rows of those steps are not written). */
 int bat_rollout(bat_engine* e, const float* bids_ring_dev, int32_t ring_len, int32_t steps, float* obs_dev, double* reward_dev,
                 uint8_t* terminated_dev, float* obs_traj_dev, double* reward_traj_dev);
+/* The same with the trajectory rows `traj_pitch` floats apart (even, >= 4k+6): obs_traj_dev is [steps][N][traj_pitch], row
+ * (i, env) starts at ((i * N) + env) * traj_pitch and holds 4k+6 floats; what lies behind them is not written.  A pitch of
+ * 160 floats (640 B; the default of BatteryDispatchVectorEnv.rollout, which hands out the [steps, N, 4k+6] view) puts every row
+ * on a 128-byte line boundary: full-line stores instead of 600-byte rows that straddle lines (round 5). */
+int bat_rollout_pitched(bat_engine* e, const float* bids_ring_dev, int32_t ring_len, int32_t steps, float* obs_dev, double* reward_dev,
+                        uint8_t* terminated_dev, float* obs_traj_dev, int32_t traj_pitch, double* reward_traj_dev);
 /* the same with host buffers (staged through engine-owned device buffers) */
 int bat_reset_host(bat_engine* e, const int32_t* slots, float* obs_host);
 int bat_step_host(bat_engine* e, const float* bids_host, float* obs_host, double* reward_host,

@@ -124,6 +124,7 @@ BAT_SIGNATURES = {
     'bat_reset': (_i32, [_vp, _vp, _vp]),
     'bat_step': (_i32, [_vp, _vp, _vp, _vp, _vp]),
     'bat_rollout': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'bat_rollout_pitched': (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     'bat_reset_host': (_i32, [_vp, _vp, _vp]),
     'bat_step_host': (_i32, [_vp, _vp, _vp, _vp, _vp]),
     'bat_get_state': (_i32, [_vp, _vp, _vp]),

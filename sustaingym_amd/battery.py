@@ -129,14 +129,23 @@ class BatteryDispatchVectorEnv:
         assert bids_ring.dim() == 3 and tuple(bids_ring.shape[1:]) == (self.N, 2 * self.k)
         obs, rew, term = self._device_buffers()
         traj = None
+        pitch = self.F
         if trajectory:
-            traj = out if out is not None else (torch.empty((steps, self.N, self.F), dtype=torch.float32, device=obs.device),
-                                                torch.empty((steps, self.N), dtype=torch.float64, device=obs.device))
-            assert tuple(traj[0].shape) == (steps, self.N, self.F) and tuple(traj[1].shape) == (steps, self.N)
-        self._check(self.lib.bat_rollout(self.handle, C.c_void_p(bids_ring.data_ptr()), int(bids_ring.shape[0]), int(steps),
-                                         C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(term.data_ptr()),
-                                         C.c_void_p(traj[0].data_ptr()) if traj else None,
-                                         C.c_void_p(traj[1].data_ptr()) if traj else None), 'bat_rollout')
+            if out is None:
+                # rows 640 B apart (a multiple of the 128-byte line; bat_rollout_pitched): the [steps, N, 4k+6] VIEW is handed out.
+                # Zero-filled: the rows of steps after an environment's termination are not written by the kernel.
+                pitch = (self.F + 31) // 32 * 32
+                store = torch.zeros((steps, self.N, pitch), dtype=torch.float32, device=obs.device)
+                traj = (store[:, :, :self.F], torch.zeros((steps, self.N), dtype=torch.float64, device=obs.device))
+            else:
+                traj = out
+                assert tuple(traj[0].shape) == (steps, self.N, self.F) and tuple(traj[1].shape) == (steps, self.N)
+                assert traj[0].stride(2) == 1 and traj[0].stride(0) == self.N * traj[0].stride(1), 'obs_traj: rows at a constant pitch'
+                pitch = int(traj[0].stride(1))
+        self._check(self.lib.bat_rollout_pitched(self.handle, C.c_void_p(bids_ring.data_ptr()), int(bids_ring.shape[0]), int(steps),
+                                                 C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(term.data_ptr()),
+                                                 C.c_void_p(traj[0].data_ptr()) if traj else None, pitch,
+                                                 C.c_void_p(traj[1].data_ptr()) if traj else None), 'bat_rollout')
         return (obs, rew, term) + ((traj,) if traj else ())
 
     def make_stepper(self):

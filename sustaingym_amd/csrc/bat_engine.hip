@@ -117,10 +117,10 @@ __global__ __launch_bounds__(256) void bat_step_kernel(BatParams P, const float*
     const float* mfc = P.moer_fc + (size_t)slot * (BAT_TRACE_LEN + k) + t + 2;
     // forecast floats of the pairs: sources are only 4-byte aligned (they start at t + 2): one float load per element
     float2 fcopy[kPairPasses];
-    auto forecast = [&](int i) -> float {                           // output float i, if it is a forecast
-        if (i >= 5 + 2 * k && i < 5 + 3 * k) return lfc[i - (5 + 2 * k)];
-        if (i >= 6 + 3 * k && i < 6 + 4 * k) return mfc[i - (6 + 3 * k)];
-        return 0.0f;
+    auto forecast = [&](int i) -> float {                           // output float i, if it is a forecast (one load, source by address)
+        const bool is_l = i >= 5 + 2 * k && i < 5 + 3 * k, is_m = i >= 6 + 3 * k && i < 6 + 4 * k;
+        const float* src = is_l ? lfc + (i - (5 + 2 * k)) : mfc + (i - (6 + 3 * k));
+        return (is_l || is_m) ? *src : 0.0f;
     };
 #pragma unroll
     for (int j = 0; j < kPairPasses; j++) {
@@ -174,86 +174,130 @@ __global__ __launch_bounds__(256) void bat_step_kernel(BatParams P, const float*
 }
 
 // T steps per launch (bat_rollout): the step above in a loop, state in registers.  Same geometry (a 16-lane row per
-// environment, the observation row as 8-byte pairs).  The bids of step i + 1 are requested before step i is computed and the
-// trace values of step i + 1 are known addresses (t advances by one), so a row always has one step's loads in flight behind
-// the stores of the step before: with a trajectory buffer the launch is a stream of 2k-float reads and (4k+6)-float writes
-// per environment-step and nothing else.
-// LPE = lanes per environment: 16 (the step kernel's geometry: 4 096 wavefronts for 16 384 environments, 4 per SIMD) or 64 (a
-// wavefront per environment: four times as many loops in flight — measured slower, see bat_rollout).
-template <int LPE>
+// environment, the observation row as 8-byte pairs).  Everything step i + 1 reads — its bid row, the three trace values, the
+// forecast floats of its observation — is requested one step AHEAD, before the stores of step i are issued, so that a row always
+// has one step's loads in flight behind the stores of the step before: with a trajectory buffer the launch is a stream of 2k-float
+// reads and (4k+6)-float writes per environment-step and nothing else.
+// Round 5: every memory operation of the loop is a RAW BUFFER access issued unconditionally, predicates folded into the offset
+// (kBatOob = dropped by the hardware range check).  The round-4 form used pointer loads / stores behind exec-mask branches
+// (`if (pr < F / 2) row[pr] = v`, two conditional loads into one register for the forecast floats): the compiler cannot count
+// memory operations across such branches, so every consumer of a loaded value waited with s_waitcnt vmcnt(0) — i.e. for the
+// STORES of the previous step as well (vmcnt retires in order): six full drains per step, 5.5 us per step at 0.34 of HBM peak.
+// LPE = lanes per environment: 16 (the step kernel's geometry: 4 096 wavefronts for 16 384 environments, 4 per SIMD) or 64.
+typedef __amdgpu_buffer_rsrc_t bat_rsrc_t;
+typedef unsigned bat_v2u __attribute__((ext_vector_type(2)));
+constexpr unsigned kBatOob = 0xfffffff0u;
+__device__ __forceinline__ bat_rsrc_t bat_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(unsigned)(bytes > 0xffffff00ull ? 0xffffff00ull : bytes), 0x00020000);
+}
+__device__ __forceinline__ float bat_ld_f32(bat_rsrc_t r, unsigned off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0)); }
+__device__ __forceinline__ float2 bat_ld_f32x2(bat_rsrc_t r, unsigned off) {
+    const bat_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+template <int AUX = 0>
+__device__ __forceinline__ void bat_st_f32x2(bat_rsrc_t r, unsigned off, float2 x) {
+    bat_v2u v;
+    v.x = __float_as_uint(x.x); v.y = __float_as_uint(x.y);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, AUX);
+}
+__device__ __forceinline__ void bat_st_f64(bat_rsrc_t r, unsigned off, double x) {
+    bat_v2u v;
+    v.x = (unsigned)__double2loint(x); v.y = (unsigned)__double2hiint(x);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, 0);
+}
+
+// TRAJ: with a trajectory buffer (every step's observation row is stored: bid pairs and forecast floats are loaded every step);
+// without one a step reads five scalars and stores nothing but the optional reward.  The LAST live step's observation row (the
+// persistent `obs` output) is rebuilt after the loop from what the loop kept of that step, in both forms.
+// NT: trajectory rows start on 128-byte lines and are a whole number of lines long (pitch % 32 == 0, aligned base): their stores
+// carry the non-temporal hint (written once, read by somebody else much later): 3.77 -> 3.28 us per step.  Packed 600-byte rows
+// straddle lines and must merge in L2: with nt they lose (3.9 -> 5.4), so they keep the default policy.
+template <int LPE, bool TRAJ, bool NT>
 __global__ __launch_bounds__(256) void bat_rollout_kernel(BatParams P, const float* __restrict__ ring, int ring_len, int steps,
                                                           float* __restrict__ obs, double* __restrict__ reward,
                                                           unsigned char* __restrict__ terminated, float* __restrict__ obs_traj,
-                                                          double* __restrict__ reward_traj) {
+                                                          int traj_pitch, double* __restrict__ reward_traj) {
     const int q = threadIdx.x & (LPE - 1);
-    const int env = (blockIdx.x * 256 + threadIdx.x) / LPE;
-    if (env >= P.N) return;
+    const int env_i = (blockIdx.x * 256 + threadIdx.x) / LPE;
+    const bool ev = env_i < P.N;                       // rows past N issue the same accesses, all out of range
+    const unsigned env = ev ? (unsigned)env_i : 0u;
     const int k = P.k, F = P.F;
+    const unsigned N = (unsigned)P.N;
     constexpr int kPairPasses = ((4 * BAT_MAX_FORECAST + 6) / 2 + LPE - 1) / LPE;
-    int t = P.t[env];
-    const int slot = P.slot[env];
-    double e = P.energy[env];
-    double ret = P.ret[env];
+    int t = ev ? P.t[env] : BAT_EPISODE_STEPS;
+    const unsigned slot = ev ? (unsigned)P.slot[env] : 0u;
+    double e = ev ? P.energy[env] : 0.0;
+    double ret = ev ? P.ret[env] : 0.0;
     const double term_price = P.terminal_price[slot];
-    const float* price = P.price + (size_t)slot * BAT_TRACE_LEN;
-    const float* load = P.load + (size_t)slot * BAT_TRACE_LEN;
-    const float* moer = P.moer + (size_t)slot * BAT_TRACE_LEN;
-    const float* lfc0 = P.load_fc + (size_t)slot * (BAT_TRACE_LEN + k);
-    const float* mfc0 = P.moer_fc + (size_t)slot * (BAT_TRACE_LEN + k);
-    const size_t row_bids = (size_t)2 * k, batch_bids = (size_t)P.N * row_bids;
-    auto load_bids = [&](int i, float2 (&dst)[kPairPasses], float& bc, float& bd) {
-        const float* a = ring + (size_t)(i % ring_len) * batch_bids + (size_t)env * row_bids;
-        bc = a[0];
-        bd = a[k];
+    const unsigned S = (unsigned)P.bank_slots, Tk = (unsigned)(BAT_TRACE_LEN + k);
+    const bat_rsrc_t r_ring = bat_rsrc(ring, (size_t)ring_len * N * 2u * k * 4u);
+    const bat_rsrc_t r_price = bat_rsrc(P.price, (size_t)S * BAT_TRACE_LEN * 4u), r_load = bat_rsrc(P.load, (size_t)S * BAT_TRACE_LEN * 4u),
+                     r_moer = bat_rsrc(P.moer, (size_t)S * BAT_TRACE_LEN * 4u);
+    // the two forecast tables are ONE allocation (bat_create): [load_fc | moer_fc], so that a lane picks its table by offset
+    const bat_rsrc_t r_fc = bat_rsrc(P.load_fc, (size_t)2u * S * Tk * 4u);
+    const bat_rsrc_t r_obs = bat_rsrc(obs, (size_t)N * F * 4u);
+    const bat_rsrc_t r_rt = bat_rsrc(reward_traj, reward_traj ? (size_t)steps * N * 8u : 0u);
+    const unsigned row_bids = 2u * (unsigned)k * 4u, batch_bids = N * row_bids;
+    struct StepIn { float2 a[TRAJ ? kPairPasses : 1], f[TRAJ ? kPairPasses : 1]; float bc, bd, pf, lf, mf; };
+    // the bid pairs and forecast floats of the observation row after step i (taken at period tt)
+    auto fetch_row = [&](int i, int tt, bool on, float2 (&a)[kPairPasses], float2 (&f)[kPairPasses]) {
+        const unsigned base = (unsigned)(i % ring_len) * batch_bids + env * row_bids;
+        const unsigned tc = (unsigned)(tt < BAT_EPISODE_STEPS ? tt : BAT_EPISODE_STEPS - 1);
+        const unsigned fc0 = slot * Tk + tc + 2u;              // lhat / mhat of the NEXT observation start at t1 + 1
 #pragma unroll
         for (int j = 0; j < kPairPasses; j++) {
             const int pr = q + LPE * j;
-            dst[j] = (pr >= 1 && pr <= k) ? *reinterpret_cast<const float2*>(a + 2 * (pr - 1)) : make_float2(0.0f, 0.0f);
-        }
-    };
-    // everything step i reads — its bid row, the three trace values, the forecast floats of its observation — is requested one
-    // step AHEAD, before the stores of step i - 1 are issued: vmcnt retires in order, so a load issued behind a store waits for
-    // that store's acknowledgement (the first form of this loop did: one write latency per step, 5.3 us per step)
-    struct StepIn { float2 a[kPairPasses], f[kPairPasses]; float bc, bd, pf, lf, mf; };
-    auto fetch = [&](int i, int tt, bool rows, StepIn& in) {
-        load_bids(i, in.a, in.bc, in.bd);
-        const int tc = tt < BAT_EPISODE_STEPS ? tt : BAT_EPISODE_STEPS - 1;      // (a step after the end reads nothing it uses)
-        in.pf = price[tc]; in.lf = load[tc]; in.mf = moer[tc];
-        const float* lfc = lfc0 + tc + 2;
-        const float* mfc = mfc0 + tc + 2;
-#pragma unroll
-        for (int j = 0; j < kPairPasses; j++) {
+            a[j] = bat_ld_f32x2(r_ring, (on && pr >= 1 && pr <= k) ? base + 8u * (unsigned)(pr - 1) : kBatOob);
             float v[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int ii = 2 * (q + LPE * j) + h;
-                v[h] = 0.0f;
-                if (rows) {
-                    if (ii >= 5 + 2 * k && ii < 5 + 3 * k) v[h] = lfc[ii - (5 + 2 * k)];
-                    if (ii >= 6 + 3 * k && ii < 6 + 4 * k) v[h] = mfc[ii - (6 + 3 * k)];
-                }
+                const int ii = 2 * pr + h;
+                const bool is_l = ii >= 5 + 2 * k && ii < 5 + 3 * k, is_m = ii >= 6 + 3 * k && ii < 6 + 4 * k;
+                const unsigned idx = is_l ? fc0 + (unsigned)(ii - (5 + 2 * k)) : S * Tk + fc0 + (unsigned)(ii - (6 + 3 * k));
+                v[h] = bat_ld_f32(r_fc, (on && (is_l || is_m)) ? idx * 4u : kBatOob);
             }
-            in.f[j] = make_float2(v[0], v[1]);
+            f[j] = make_float2(v[0], v[1]);
         }
     };
-    const bool every_row = obs_traj != nullptr;
+    // everything step i reads, for the environment's period tt; `on` = the step exists and the row is still running
+    auto fetch = [&](int i, int tt, bool on, StepIn& in) {
+        const unsigned base = (unsigned)(i % ring_len) * batch_bids + env * row_bids;
+        in.bc = bat_ld_f32(r_ring, on ? base : kBatOob);
+        in.bd = bat_ld_f32(r_ring, on ? base + (unsigned)k * 4u : kBatOob);
+        const unsigned tc = (unsigned)(tt < BAT_EPISODE_STEPS ? tt : BAT_EPISODE_STEPS - 1);
+        const unsigned tr = on ? (slot * BAT_TRACE_LEN + tc) * 4u : kBatOob;
+        in.pf = bat_ld_f32(r_price, tr); in.lf = bat_ld_f32(r_load, tr); in.mf = bat_ld_f32(r_moer, tr);
+        if constexpr (TRAJ) fetch_row(i, tt, on, in.a, in.f);
+    };
+    auto row_value = [&](int pr, float2 a, float2 f, int t1, double e1, double x, float pf, float lf, float mf) {
+        float2 v = (pr >= 1 && pr <= k) ? a : f;
+        auto scalar = [&](int ii, float w) -> float {
+            if (ii == 0) return (float)t1;
+            if (ii == 1) return (float)e1;
+            if (ii == 2 + 2 * k) return (float)x;
+            if (ii == 3 + 2 * k) return pf;
+            if (ii == 4 + 2 * k) return lf;
+            if (ii == 5 + 3 * k) return mf;
+            return w;
+        };
+        v.x = scalar(2 * pr, v.x);
+        v.y = scalar(2 * pr + 1, v.y);
+        return pr < F / 2 ? v : make_float2(0.0f, 0.0f);
+    };
     StepIn cur, nxt;
-    fetch(0, t, every_row || steps == 1 || t + 1 >= BAT_EPISODE_STEPS, cur);
+    fetch(0, t, t < BAT_EPISODE_STEPS, cur);
     double r = 0.0;
     bool done = t >= BAT_EPISODE_STEPS;
+    // the last live step, for the `obs` row: its index and the scalars of its observation (t and e are the final state)
+    int i_last = -1;
+    double x_last = 0.0;
+    float pf_last = 0.0f, lf_last = 0.0f, mf_last = 0.0f;
     for (int i = 0; i < steps; i++) {
-        if (t >= BAT_EPISODE_STEPS) {                  // steps after termination: no-ops, reward 0
-            r = 0.0;
-            done = true;
-            if (reward_traj && q == 0)
-                for (int j = i; j < steps; j++) reward_traj[(size_t)j * P.N + env] = 0.0;
-            break;
-        }
+        const bool act = t < BAT_EPISODE_STEPS;          // steps after termination: no-ops, reward 0 (rows of obs_traj not written)
         const int t1 = t + 1;
-        done = t1 >= BAT_EPISODE_STEPS;
-        const bool last = i + 1 == steps || done;
-        const bool want_row = every_row || last;
-        if (i + 1 < steps) fetch(i + 1, t1, every_row || i + 2 == steps || t1 + 1 >= BAT_EPISODE_STEPS, nxt);
+        const bool done1 = t1 >= BAT_EPISODE_STEPS;
+        fetch(i + 1, t1, act && !done1 && i + 1 < steps, nxt);
         const float pf = cur.pf, lf = cur.lf, mf = cur.mf;
         const double p = (double)pf, m = (double)mf;
         const bool sell = p >= (double)cur.bd, buy = p <= (double)cur.bc;
@@ -266,39 +310,45 @@ __global__ __launch_bounds__(256) void bat_rollout_kernel(BatParams P, const flo
             e1 = e - P.eta_c * x;
         }
         e1 = fmin(fmax(e1, 0.0), P.cap);
-        r = p * x + P.pco2 * m * x;
-        if (done) r -= term_price * fmax(0.0, P.e0 - e1);
-        if (want_row) {
-            auto scalar = [&](int ii, float v) -> float {
-                if (ii == 0) return (float)t1;
-                if (ii == 1) return (float)e1;
-                if (ii == 2 + 2 * k) return (float)x;
-                if (ii == 3 + 2 * k) return pf;
-                if (ii == 4 + 2 * k) return lf;
-                if (ii == 5 + 3 * k) return mf;
-                return v;
-            };
-            float2* row_last = reinterpret_cast<float2*>(obs + (size_t)env * F);
-            float2* row_traj = obs_traj ? reinterpret_cast<float2*>(obs_traj + ((size_t)i * P.N + env) * F) : nullptr;
+        double ri = p * x + P.pco2 * m * x;
+        if (done1) ri -= term_price * fmax(0.0, P.e0 - e1);
+        if constexpr (TRAJ) {
+            // trajectory rows at the caller's pitch (floats): the descriptor of step i's slab [N][pitch]; the padding behind the
+            // 4k+6 floats is written too (zeros) so that whole lines go out
+            const bat_rsrc_t r_traj = bat_rsrc(obs_traj + (size_t)i * N * (size_t)traj_pitch, (size_t)N * (size_t)traj_pitch * 4u);
 #pragma unroll
             for (int j = 0; j < kPairPasses; j++) {
                 const int pr = q + LPE * j;
-                float2 v = (pr >= 1 && pr <= k) ? cur.a[j] : cur.f[j];
-                v.x = scalar(2 * pr, v.x);
-                v.y = scalar(2 * pr + 1, v.y);
-                if (pr < F / 2) {
-                    if (row_traj) row_traj[pr] = v;
-                    if (last) row_last[pr] = v;
-                }
+                const float2 v = row_value(pr, cur.a[j], cur.f[j], t1, e1, x, pf, lf, mf);
+                bat_st_f32x2<NT ? 2 : 0>(r_traj, (act && ev && pr < traj_pitch / 2) ? (env * (unsigned)traj_pitch + 2u * (unsigned)pr) * 4u : kBatOob, v);
             }
         }
-        if (reward_traj && q == 0) reward_traj[(size_t)i * P.N + env] = r;
-        ret += r;
-        e = e1;
-        t = t1;
+        bat_st_f64(r_rt, (ev && q == 0) ? ((unsigned)i * N + env) * 8u : kBatOob, act ? ri : 0.0);
+        if (act) {
+            r = ri;
+            ret += ri;
+            e = e1;
+            t = t1;
+            done = done1;
+            i_last = i; x_last = x; pf_last = pf; lf_last = lf; mf_last = mf;
+        } else {
+            r = 0.0;
+            done = true;
+        }
         cur = nxt;
     }
-    if (q == 0) {
+    {   // `obs` row of the last live step (none: the environment had ended before the call; its row stays as it was)
+        const bool on = ev && i_last >= 0;
+        float2 a[kPairPasses], f[kPairPasses];
+        fetch_row(i_last < 0 ? 0 : i_last, t - 1, on, a, f);
+#pragma unroll
+        for (int j = 0; j < kPairPasses; j++) {
+            const int pr = q + LPE * j;
+            const float2 v = row_value(pr, a[j], f[j], t, e, x_last, pf_last, lf_last, mf_last);
+            bat_st_f32x2(r_obs, (on && pr < F / 2) ? (env * (unsigned)F + 2u * (unsigned)pr) * 4u : kBatOob, v);
+        }
+    }
+    if (q == 0 && ev) {
         P.energy[env] = e;
         P.t[env] = t;
         P.ret[env] = ret;
@@ -363,7 +413,9 @@ int bat_create(const bat_config* cfg, bat_engine** out) {
 #define BA(ptr, bytes) do { if (alloc((void**)&(ptr), (bytes)) != hipSuccess) { bat_destroy(e); return fail(-3, "bat_create: hipMalloc failed"); } } while (0)
     BA(P.energy, N * 8); BA(P.ret, N * 8); BA(P.t, N * 4); BA(P.slot, N * 4);
     BA(P.price, S * BAT_TRACE_LEN * 4); BA(P.load, S * BAT_TRACE_LEN * 4); BA(P.moer, S * BAT_TRACE_LEN * 4);
-    BA(P.load_fc, S * (BAT_TRACE_LEN + k) * 4); BA(P.moer_fc, S * (BAT_TRACE_LEN + k) * 4); BA(P.terminal_price, S * 8);
+    BA(P.load_fc, 2 * S * (BAT_TRACE_LEN + k) * 4);      // [load_fc | moer_fc]: one allocation (bat_rollout_kernel picks the table by offset)
+    P.moer_fc = P.load_fc + S * (BAT_TRACE_LEN + k);
+    BA(P.terminal_price, S * 8);
     BA(e->d_slots, N * 4); BA(e->d_bids, N * 2 * k * 4); BA(e->d_obs, N * (4 * k + 6) * 4); BA(e->d_reward, N * 8);
     BA(e->d_term, N); BA(e->d_metrics, 4 * 8);
 #undef BA
@@ -425,19 +477,38 @@ int bat_step(bat_engine* e, const float* bids_dev, float* obs_dev, double* rewar
 
 int bat_rollout(bat_engine* e, const float* bids_ring_dev, int32_t ring_len, int32_t steps, float* obs_dev, double* reward_dev,
                 uint8_t* terminated_dev, float* obs_traj_dev, double* reward_traj_dev) {
+    return bat_rollout_pitched(e, bids_ring_dev, ring_len, steps, obs_dev, reward_dev, terminated_dev, obs_traj_dev,
+                               e ? e->P.F : 0, reward_traj_dev);
+}
+
+int bat_rollout_pitched(bat_engine* e, const float* bids_ring_dev, int32_t ring_len, int32_t steps, float* obs_dev, double* reward_dev,
+                        uint8_t* terminated_dev, float* obs_traj_dev, int32_t traj_pitch, double* reward_traj_dev) {
     if (!e || !bids_ring_dev || !obs_dev || !reward_dev || !terminated_dev) return fail(-1, "bat_rollout: null argument");
     if (ring_len < 1 || steps < 1) return fail(-1, "bat_rollout: ring_len and steps must be >= 1");
+    if (obs_traj_dev && (traj_pitch < e->P.F || (traj_pitch & 1)))
+        return fail(-1, "bat_rollout: trajectory pitch %d must be even and >= the observation width %d", traj_pitch, e->P.F);
     HIP_TRY(hipSetDevice(e->device));
     // lanes per environment: 16 = the step kernel's geometry (default); 64 = a wavefront per environment, measured SLOWER
     // (7.2 against 5.5 us per 16 384-environment step with a trajectory, 3.0 against 1.6 without): the loop is not short of
     // loops in flight.  BAT_ROLLOUT_LPE=64 selects it (measurements).
     static const int lpe = getenv("BAT_ROLLOUT_LPE") ? atoi(getenv("BAT_ROLLOUT_LPE")) : 16;
-    if (lpe == 16)
-        hipLaunchKernelGGL(bat_rollout_kernel<16>, dim3((e->P.N + 15) / 16), dim3(256), 0, e->stream, e->P, bids_ring_dev, ring_len, steps,
-                           obs_dev, reward_dev, terminated_dev, obs_traj_dev, reward_traj_dev);
-    else
-        hipLaunchKernelGGL(bat_rollout_kernel<64>, dim3((e->P.N + 3) / 4), dim3(256), 0, e->stream, e->P, bids_ring_dev, ring_len, steps,
-                           obs_dev, reward_dev, terminated_dev, obs_traj_dev, reward_traj_dev);
+    if (lpe != 16 && lpe != 64) return fail(-1, "BAT_ROLLOUT_LPE=%d: 16 or 64", lpe);
+#define BAT_LAUNCH_ROLLOUT(L, T, NTF, GRID)                                                                                    \
+    hipLaunchKernelGGL((bat_rollout_kernel<L, T, NTF>), dim3(GRID), dim3(256), 0, e->stream, e->P, bids_ring_dev, ring_len, steps, obs_dev, \
+                       reward_dev, terminated_dev, obs_traj_dev, traj_pitch, reward_traj_dev)
+    const bool traj = obs_traj_dev != nullptr;
+    const bool lines = traj && traj_pitch % 32 == 0 && ((uintptr_t)obs_traj_dev & 127u) == 0;
+    const int g16 = (e->P.N + 15) / 16, g64 = (e->P.N + 3) / 4;
+    if (lpe == 16) {
+        if (!traj) BAT_LAUNCH_ROLLOUT(16, false, false, g16);
+        else if (lines) BAT_LAUNCH_ROLLOUT(16, true, true, g16);
+        else BAT_LAUNCH_ROLLOUT(16, true, false, g16);
+    } else {
+        if (!traj) BAT_LAUNCH_ROLLOUT(64, false, false, g64);
+        else if (lines) BAT_LAUNCH_ROLLOUT(64, true, true, g64);
+        else BAT_LAUNCH_ROLLOUT(64, true, false, g64);
+    }
+#undef BAT_LAUNCH_ROLLOUT
     HIP_TRY(hipGetLastError());
     e->env_steps += (unsigned long long)e->P.N * (unsigned long long)steps;
     return 0;
