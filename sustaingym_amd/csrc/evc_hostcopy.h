@@ -79,6 +79,23 @@ public:
         return hipStreamSynchronize(stream);
     }
 
+    // Page-locked host memory only: the copy is ENQUEUED on `stream` and not waited for (the caller synchronises once, behind
+    // several of them); returns false — nothing enqueued — for pageable memory, which goes through d2h / h2d above.
+    static bool d2h_async(void* dst, const void* src_dev, size_t bytes, hipStream_t stream, hipError_t& rc) {
+        rc = hipSuccess;
+        if (bytes == 0) return true;
+        if (!is_pinned(dst)) return false;
+        rc = hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, stream);
+        return true;
+    }
+    static bool h2d_async(void* dst_dev, const void* src, size_t bytes, hipStream_t stream, hipError_t& rc) {
+        rc = hipSuccess;
+        if (bytes == 0) return true;
+        if (!is_pinned(src)) return false;
+        rc = hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, stream);
+        return true;
+    }
+
     // One copier per DEVICE (the calling engine has made its device current): HIP events belong to the device that was
     // current when they were created and cannot be recorded on another device's stream, so a single process-wide set
     // would break the second engine of a process that drives two GPUs.  The buffers live until the process ends.
