@@ -474,15 +474,19 @@ def secondary_rollout(policy, dev_index, battery, episodes='synthetic', site='ca
     # The fused kernel has no HBM traffic to speak of (one MOER value and the arriving session records per environment-period):
     # its bound is VALU issue.  Instructions per env-step come from the SQ counters of tools/profile_rollout.sh
     # (profiles/r3_rollout_*.json); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md).
-    valu = None
-    try:
-        valu = json.load(open(os.path.join(ROOT, 'profiles', f'r3_rollout_{site}_{"synthetic" if episodes == "synthetic" else "gmm"}_{policy}.json')))['SQ_INSTS_VALU']
-    except Exception:
-        pass
+    valu = valu_src = None
+    for rnd in ('r5', 'r3'):                              # the newest committed SQ-counter record of this workload
+        try:
+            valu_src = f'profiles/{rnd}_rollout_{site}_{"synthetic" if episodes == "synthetic" else "gmm"}_{policy}.json'
+            valu = json.load(open(os.path.join(ROOT, valu_src)))['SQ_INSTS_VALU']
+            break
+        except Exception:
+            valu_src = None
     peak = 256 * 4 * 2.4e9 / 2
     roof = None if valu is None else {'bound': 'valu', 'valu_instructions_per_env_step': valu,
                                       'achieved': round(N * EPISODE / (kernel_ms * 1e-3) * valu / 1e9, 1), 'peak': round(peak / 1e9, 1),
                                       'unit': 'G wave-instructions/s', 'frac': round(N * EPISODE / (kernel_ms * 1e-3) * valu / peak, 4),
+                                      'instructions_from': valu_src,
                                       'note': 'float64 instructions issue at half this rate; SQ_ACTIVE_INST_VALU says the vector ALUs are busy ~68 % of the launch (DESIGN.md 4.6)'}
     return {'workload': f'{N} x {w.n}-station ({site}), {"synthetic days" if episodes == "synthetic" else "device-generated GMM days"}, '
                         f'projection on, {policy} policy on the device, whole episodes (288 periods), autoreset',
