@@ -1534,8 +1534,8 @@ int evc_debug_read_slow_list(evc_engine* e, int* out, int count) {
 #endif
 
 #ifdef EVC_SOLVER_STATS
-int evc_debug_solver_stats(unsigned long long* out8 /* [16] */) {
-    static const unsigned long long zero[16] = {0};
+int evc_debug_solver_stats(unsigned long long* out8 /* [32] */) {
+    static const unsigned long long zero[32] = {0};
     if (hipDeviceSynchronize() != hipSuccess) return -4;
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(evc::g_solver_stats), sizeof(zero)) != hipSuccess) return -4;
     if (hipMemcpyToSymbol(HIP_SYMBOL(evc::g_solver_stats), zero, sizeof(zero)) != hipSuccess) return -4;

@@ -27,7 +27,7 @@ constexpr int kMaxDim = 2 * kMaxActive;
 constexpr int kSolverMaxIter = 60;
 
 #ifdef EVC_SOLVER_STATS   // diagnostic builds only (tools/build_variant.sh): work statistics of the slow kernel
-__device__ unsigned long long g_solver_stats[16];
+__device__ unsigned long long g_solver_stats[32];
 #define SOLVER_CLK() clock64()
 #define SOLVER_STAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_solver_stats[i], (unsigned long long)(v)); } while (0)
 #else
@@ -516,6 +516,101 @@ __device__ __forceinline__ bool wave_cone(const LdsNet& net, int gid, double b, 
     return false;
 }
 
+// Round 5 — ONE cone row beside class caps, with the caps ELIMINATED instead of carried as rows of their own (what (b2) below does
+// with wave_cone<2|3>: a 4- or 6-dimensional Newton whose every iteration costs 6 float64 wave sums, 21 more whenever the clamp
+// pattern moves, and a 6 x 6 elimination — 34 k cycles per Caltech midday residual, profiles/r5_solver_stats.txt, and the launch waits
+// for it).  The relaxed problem  min |y - b|^2  s.t. box, every class cap, row c  has the KKT form
+//     y_i = clip(b_i - M_g . z - nu_g, 0, h_i),   nu_g >= 0 only where class g sits AT its cap,   w = sum_g M_g S_g = limit z / |z|
+// (M_g = the row's phasor coefficient of class g, z in R^2 the row's multiplier).  For a given z a capped class contributes exactly
+// S_g = cap_g — its nu_g need not be known to evaluate w — and nothing to the Jacobian, so the Newton iteration runs on z alone
+// (2 x 2), one wave sum per class of the row per iteration, the free counts from ballots; the caps' inner fillings are done once, at
+// the end.  Same residual, shift and tolerance as wave_cone<1>; anything irregular returns false and the chain below takes over.
+// yw = the schedule after the caps' filling (kept by classes the row does not load).  The caller verifies every row and cap.
+__device__ __forceinline__ bool wave_cone_capped(const Params& P, const LdsNet& net, int gid, int c, double b, double h, double yw,
+                                                 double& yout) {
+    const int G = P.G;
+    const double c0 = gid >= 0 ? net.Mre[gid][c] : 0.0, c1 = gid >= 0 ? net.Mim[gid][c] : 0.0;
+    const bool in_row = c0 != 0.0 || c1 != 0.0;
+    const double rmag = net.mag[c];
+    // the classes the row loads, once: coefficient, cap, class id in registers (wave-uniform); a row over more than kRowClasses
+    // classes is left to the chain below
+    constexpr int kRowClasses = 6;
+    double m0[kRowClasses], m1[kRowClasses], capv[kRowClasses];
+    int cls[kRowClasses];
+    int nc = 0;
+#pragma unroll
+    for (int j = 0; j < kRowClasses; j++) { m0[j] = 0.0; m1[j] = 0.0; capv[j] = HUGE_VAL; cls[j] = -1; }
+    for (int g = 0; g < G; g++) {
+        const double a0 = net.Mre[g][c], a1 = net.Mim[g][c];
+        if (a0 == 0.0 && a1 == 0.0) continue;
+        if (nc >= kRowClasses) return false;
+#pragma unroll
+        for (int j = 0; j < kRowClasses; j++)
+            if (j == nc) { m0[j] = a0; m1[j] = a1; capv[j] = P.class_cap[g]; cls[j] = g; }
+        nc++;
+    }
+    double z0 = 0.0, z1 = 0.0, mu = 1e-3;
+    unsigned capped = 0u;
+    for (int it = 0; it < 20; it++) {
+        const double v = b - (c0 * z0 + c1 * z1);
+        const double y = in_row ? fmin(fmax(v, 0.0), h) : 0.0;
+        const bool fr = in_row && v > 0.0 && v <= h && h > 0.0;
+        double w0 = 0.0, w1 = 0.0, K00 = 0.0, K01 = 0.0, K11 = 0.0;
+        capped = 0u;
+        double Wg[kRowClasses];
+#pragma unroll
+        for (int j = 0; j < kRowClasses; j++) Wg[j] = j < nc ? wave_sum_f64(gid == cls[j] ? y : 0.0) : 0.0;      // independent ladders
+#pragma unroll
+        for (int j = 0; j < kRowClasses; j++) {
+            if (j >= nc) continue;
+            double Sg = Wg[j];
+            if (Wg[j] > capv[j]) { Sg = capv[j]; capped |= 1u << cls[j]; }
+            else {
+                const double kg = (double)__popcll(__ballot(fr && gid == cls[j]));
+                K00 += kg * m0[j] * m0[j]; K01 += kg * m0[j] * m1[j]; K11 += kg * m1[j] * m1[j];
+            }
+            w0 += m0[j] * Sg; w1 += m1[j] * Sg;
+        }
+        if (it == 0) {                                   // first-order size along w (as wave_cone<1>)
+            const double nw = sqrt(w0 * w0 + w1 * w1);
+            if (!(nw > rmag)) return false;
+            const double wh0 = w0 / nw, wh1 = w1 / nw;
+            const double curv = wh0 * (K00 * wh0 + K01 * wh1) + wh1 * (K01 * wh0 + K11 * wh1);
+            const double lam = curv > 0.0 ? fmax((nw - rmag) / curv, 1e-6) : 1e-6;
+            z0 = lam * wh0; z1 = lam * wh1;
+            continue;
+        }
+        const double inz = newton_rsqrt(z0 * z0 + z1 * z1);
+        const double zh0 = z0 * inz, zh1 = z1 * inz;
+        double g0 = w0 - rmag * zh0, g1 = w1 - rmag * zh1;
+        const double lim = Consts::PROJ_TOL_KKT * rmag;
+        if (g0 * g0 + g1 * g1 <= lim * lim) {
+            double yy = in_row ? y : yw;
+            [[maybe_unused]] const long long tf = SOLVER_CLK();
+            for (int g = 0; g < G; g++)
+                if ((capped >> g) & 1u) yy = waterfill_class(gid == g, v, h, P.class_cap[g], yy);
+            yout = yy;
+            SOLVER_STAT(24, SOLVER_CLK() - tf); SOLVER_STAT(25, __popc(capped));
+            SOLVER_STAT(20, it);
+            return true;
+        }
+        const double rn = rmag * inz;
+        double B00 = K00 + rn * (1.0 - zh0 * zh0), B11 = K11 + rn * (1.0 - zh1 * zh1), B01 = K01 - rn * zh0 * zh1;
+        double scale = 0.5 * (B00 + B11);
+        scale = scale < 1e-12 ? 1e-12 : scale;
+        B00 += mu * scale; B11 += mu * scale;
+        const double det = B00 * B11 - B01 * B01;
+        if (!(B00 > 0.0) || !(det > 0.0)) return false;
+        const double idet = newton_rcp(det);
+        const double d0 = (B11 * g0 - B01 * g1) * idet, d1 = (B00 * g1 - B01 * g0) * idet;
+        const double t0 = z0 + d0, t1 = z1 + d1;
+        if (!(t0 * z0 + t1 * z1 > 0.0)) return false;   // the row would leave the active set
+        z0 = t0; z1 = t1;
+        mu = fmax(mu * 0.25, 1e-12);
+    }
+    return false;
+}
+
 #ifndef EVC_SOLVE_ENV_INLINE
 #define EVC_SOLVE_ENV_INLINE __forceinline__
 #endif
@@ -585,6 +680,8 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
     if (!warm_start) {
         const double y0 = fmin(ln.b, ln.h);
         const ExactRows e0 = exact_rows_worst(P, L.net, lnet, lane, y0);
+        [[maybe_unused]] const long long tA = SOLVER_CLK();
+        SOLVER_STAT(15, tA - c0);
         ln.y = y0;
         if (e0.viol == 0ull) {
             settled = true;
@@ -594,12 +691,30 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
                 if ((e0.cap_viol >> g) & 1u)
                     yw = waterfill_class(lnet.gid == g, ln.b, ln.h, P.class_cap[g], yw);
             const ExactRows ew = exact_rows_worst(P, L.net, lnet, lane, yw);
+            [[maybe_unused]] const long long tB = SOLVER_CLK();
+            SOLVER_STAT(16, tB - tA);
             if (ew.viol == 0ull) {
                 ln.y = yw;
                 settled = true;
             }
+#ifndef EVC_ABL_NO_CONE_CAPPED
+            else if (ew.worst >= 0) {
+                // (b0) caps filled, a row still above its limit: that row with the caps eliminated (wave_cone_capped)
+                double yc = 0.0;
+                [[maybe_unused]] const long long tC = SOLVER_CLK();
+                if (wave_cone_capped(P, L.net, lnet.gid, ew.worst, ln.b, ln.h, yw, yc)) {
+                    SOLVER_STAT(26, SOLVER_CLK() - tC);
+                    const ExactRows ec = exact_rows_worst(P, L.net, lnet, lane, yc);
+                    if (ec.viol == 0ull && ec.cap_viol == 0u) {
+                        ln.y = yc;
+                        settled = true;
+                    }
+                }
+                SOLVER_STAT(21, SOLVER_CLK() - tC); SOLVER_STAT(22, 1); SOLVER_STAT(23, settled ? 1 : 0);
+            }
+#endif
 #ifndef EVC_ABL_NO_WAVE_CONE
-            else if (__popc(e0.cap_viol) <= 2 && ew.worst >= 0) {
+            if (!settled && ew.viol != 0ull && __popc(e0.cap_viol) <= 2 && ew.worst >= 0) {
                 // (b2) Caps filled, a row still violated (Caltech's congested middays: a feeder row beside the pod caps — one
                 // such environment per step, and its solve is what the launch waits for).  The caps' own rows and the worst
                 // remaining row, together and at once: the caps' multipliers are known from the filling (a class shifted by
@@ -643,6 +758,8 @@ __device__ __forceinline__ double solve_projection(const Params& P, SolverLds& L
                         settled = true;
                     }
                 }
+                SOLVER_STAT(17, SOLVER_CLK() - tB);          // (b2): caps' rows + worst row at once
+                SOLVER_STAT(18, 1); SOLVER_STAT(19, settled ? 1 : 0); SOLVER_STAT(20, nc);
             }
 #endif
         }
