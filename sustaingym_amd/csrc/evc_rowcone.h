@@ -263,6 +263,105 @@ __device__ __forceinline__ void quad_waterfill_bh(bool on, int g, const int (&st
         if (on && in_g[j]) y[j] = fmin(fmax(b[j] - nu, 0.0), h[j]);
 }
 
+// ONE cone row beside class caps with the caps eliminated — wave_cone_capped (evc_solver.h) in row geometry: the rows with `on`
+// solve their own constraint row c (row-uniform, different from row to row) by a 2 x 2 Newton on that row's multiplier; a class
+// above its cap contributes exactly its cap to w and nothing to the Jacobian; the inner fillings of the classes left at their cap
+// run once, at the end.  yw = the schedule after the caps' filling (kept by classes the row does not load).  Returns per row
+// whether it converged; the caller verifies every row and cap of the result.
+__device__ __forceinline__ bool quad_cone_capped(int G, const double* class_cap, const LdsNet& net, bool on, int c,
+                                                 const int (&st_gid)[kSlots], const double (&b)[kSlots], const double (&h)[kSlots],
+                                                 const double (&yw)[kSlots], double (&yout)[kSlots]) {
+    const int cc = c >= 0 ? c : 0;
+    double cf0[kSlots], cf1[kSlots];
+    bool in_row[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; j++) {
+        cf0[j] = st_gid[j] >= 0 ? net.Mre[st_gid[j]][cc] : 0.0;
+        cf1[j] = st_gid[j] >= 0 ? net.Mim[st_gid[j]][cc] : 0.0;
+        in_row[j] = cf0[j] != 0.0 || cf1[j] != 0.0;
+    }
+    const double rmag = net.mag[cc];
+    double z0 = 0.0, z1 = 0.0, mu = 1e-3;
+    bool run = on, ok = false;
+    unsigned capped = 0u;
+    double v[kSlots], y[kSlots];
+    for (int it = 0; it < 20 && __ballot(run) != 0ull; it++) {
+        bool fr[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            v[j] = b[j] - (cf0[j] * z0 + cf1[j] * z1);
+            y[j] = in_row[j] ? fmin(fmax(v[j], 0.0), h[j]) : 0.0;
+            fr[j] = in_row[j] && v[j] > 0.0 && v[j] <= h[j] && h[j] > 0.0;
+        }
+        double w0 = 0.0, w1 = 0.0, K00 = 0.0, K01 = 0.0, K11 = 0.0;
+        capped = 0u;
+        for (int g = 0; g < G; g++) {
+            const double m0 = net.Mre[g][cc], m1 = net.Mim[g][cc];              // (row-uniform)
+            const bool loads = m0 != 0.0 || m1 != 0.0;
+            if (__ballot(run && loads) == 0ull) continue;
+            double part = 0.0;
+            unsigned nf = 0u;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) {
+                part += st_gid[j] == g ? y[j] : 0.0;
+                nf += (st_gid[j] == g && fr[j]) ? 1u : 0u;
+            }
+            const double Wg = row_allreduce_f64(part);
+            const double kg = (double)row_allreduce_u32(nf);
+            if (loads) {
+                if (Wg > class_cap[g]) {
+                    capped |= 1u << g;
+                    w0 += m0 * class_cap[g]; w1 += m1 * class_cap[g];
+                } else {
+                    w0 += m0 * Wg; w1 += m1 * Wg;
+                    K00 += kg * m0 * m0; K01 += kg * m0 * m1; K11 += kg * m1 * m1;
+                }
+            }
+        }
+        if (it == 0) {                                   // first-order size along w
+            const double nw = sqrt(w0 * w0 + w1 * w1);
+            if (!(nw > rmag)) run = false;
+            const double wh0 = w0 / nw, wh1 = w1 / nw;
+            const double curv = wh0 * (K00 * wh0 + K01 * wh1) + wh1 * (K01 * wh0 + K11 * wh1);
+            const double lam = curv > 0.0 ? fmax((nw - rmag) / curv, 1e-6) : 1e-6;
+            if (run) { z0 = lam * wh0; z1 = lam * wh1; }
+            continue;
+        }
+        const double inz = newton_rsqrt(z0 * z0 + z1 * z1);
+        const double zh0 = z0 * inz, zh1 = z1 * inz;
+        const double g0 = w0 - rmag * zh0, g1 = w1 - rmag * zh1;
+        const double lim = Consts::PROJ_TOL_KKT * rmag;
+        if (run && g0 * g0 + g1 * g1 <= lim * lim) { ok = true; run = false; }
+        const double rn = rmag * inz;
+        double B00 = K00 + rn * (1.0 - zh0 * zh0), B11 = K11 + rn * (1.0 - zh1 * zh1);
+        const double B01 = K01 - rn * zh0 * zh1;
+        double scale = 0.5 * (B00 + B11);
+        scale = scale < 1e-12 ? 1e-12 : scale;
+        B00 += mu * scale; B11 += mu * scale;
+        const double det = B00 * B11 - B01 * B01;
+        if (!(B00 > 0.0) || !(det > 0.0)) run = false;
+        const double idet = newton_rcp(det);
+        const double d0 = (B11 * g0 - B01 * g1) * idet, d1 = (B00 * g1 - B01 * g0) * idet;
+        const double t0 = z0 + d0, t1 = z1 + d1;
+        if (!(t0 * z0 + t1 * z1 > 0.0)) run = false;    // the row would leave the active set
+        if (run) { z0 = t0; z1 = t1; }
+        mu = fmax(mu * 0.25, 1e-12);
+    }
+    // (a row that converged stopped updating z: v, y and `capped` are those of its last pass)
+    if (__ballot(ok) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            v[j] = b[j] - (cf0[j] * z0 + cf1[j] * z1);
+            yout[j] = in_row[j] ? fmin(fmax(v[j], 0.0), h[j]) : yw[j];
+        }
+        for (int g = 0; g < G; g++) {
+            const bool do_g = ok && ((capped >> g) & 1u);
+            if (__ballot(do_g) != 0ull) quad_waterfill_bh(do_g, g, st_gid, v, h, class_cap[g], yout);
+        }
+    }
+    return ok;
+}
+
 // solve_projection's relaxation sequence for the rows with `on`, in row geometry: exact test of the box clip -> class caps
 // by water-filling (exact if every row holds afterwards) -> one violated cap's row + the worst remaining row at once, or the
 // chain one cone row -> two.  Returns (row-uniform) whether the row is
@@ -328,6 +427,25 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
         }
         settled = settled || okw;
         open = open && !okw;
+#ifndef EVC_NO_ROW_CAPPED_CONE
+        // Round 5: two (or more) caps filled and a row still violated — three rows, which this geometry used to hand to the general
+        // path (a wavefront per environment, one after the other).  The worst row with the caps eliminated (quad_cone_capped).
+        const bool capcone = fill && !okw && ew.worst >= 0 && __popc(e0.cap_viol) >= 2;
+        if (__ballot(capcone) != 0ull) {
+            double yc[kSlots];
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) yc[j] = 0.0;
+            const bool cc = quad_cone_capped(G, class_cap, net, capcone, ew.worst, st_gid, b, h, yw, yc);
+            const RowExact ec = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, yc);
+            const bool okc = cc && ec.viol == 0u && ec.cap_viol == 0u;
+            if (okc) {
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) y[j] = yc[j];
+            }
+            settled = settled || okc;
+            open = open && !okc;
+        }
+#endif
         // The caps' own rows and multipliers, from the filling (a class shifted by nu has z_c = nu cf / |cf|^2 on its simple
         // row c): for a row the filling settled they are what the next period starts from; where a row is still violated, the
         // caps' rows and the worst remaining row are solved together (solve_projection's (b2)).
