@@ -52,7 +52,9 @@ struct RolloutLds {
     // environment, and the period (loop count + 1) they belong to — used only in the very next period
     double zwarm[4][4][16][2];
     int warm_tag[4][4];
+    int capv[4][4];                                // hand-off: the classes the period's body has filled for the row (0: none)
 };
+static_assert(sizeof(SolverWs) >= 4 * 64 * sizeof(double), "a wavefront's solver workspace doubles as the hand-off image of filled values");
 static_assert(EVC_MAX_CONSTRAINTS >= 16, "the quad geometry handles up to 16 rows");
 
 constexpr unsigned kRolloutKernargBytes = (unsigned)((((sizeof(Params) + alignof(RolloutIO) - 1) / alignof(RolloutIO)) * alignof(RolloutIO) + sizeof(RolloutIO) + 7u) & ~(size_t)7u);
@@ -81,7 +83,10 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
         const bool on = ((mask >> row) & 1u) != 0u;
         int st_gid[kSlots];
         bool is_cc[kSlots];
-        double b[kSlots], h[kSlots], y[kSlots];
+        double b[kSlots], h[kSlots], y[kSlots], ywin[kSlots];
+        // the schedule the period's body arrived at (box clip + its fillings), station-shaped, in the memory of this wavefront's
+        // solver workspace (free until the general path below needs it)
+        const double* ywimg = reinterpret_cast<const double*>(&S.ws[w]) + row * 64u;
 #pragma unroll
         for (int j = 0; j < kSlots; j++) {
             const unsigned st = (unsigned)j * 16u + q;
@@ -89,6 +94,7 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
             const unsigned info = S.st_info[st];
             st_gid[j] = valid ? (int)(info & 0x7fu) : -1;
             is_cc[j] = (info >> 7) != 0u;
+            ywin[j] = valid ? ywimg[st] : 0.0;
             h[j] = valid ? S.img[w][row][st].h_or_y : 0.0;
             b[j] = !valid ? 0.0 : (mask & 16u) ? (double)S.act_img[w][row][st] * Consts::ACTION_SCALE_FACTOR : Consts::ACTION_SCALE_FACTOR;
         }
@@ -96,7 +102,8 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
         const bool warm_ok = warm_on && tag > 1u && S.warm_tag[w][row] == (int)tag - 1;
         bool stored = false;
         const bool settled = quad_project(S.rare.G, S.rare.class_cap, S.rare.simple_rows, P.tie_counters, S.rare.tie_log2, S.net, q, (unsigned)P.m, row, on, st_gid, is_cc, b, h, y,
-                                          warm_on ? S.zwarm[w][row] : nullptr, warm_ok, &stored);
+                                          warm_on ? S.zwarm[w][row] : nullptr, warm_ok, &stored,
+                                          ywin, on ? (unsigned)S.capv[w][row] : 0u, S.rare.snap_tol);
         if (warm_on && on && settled && q == 0u) S.warm_tag[w][row] = stored ? (int)tag : 0;
         if (settled) {
 #pragma unroll
@@ -473,6 +480,15 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
 #pragma unroll
                     for (int c = 0; c < NS; c++)
                         if (solve_me && valid[c]) img_row[st[c]].h_or_y = quad_demand_cap(dep[c], rem[c]);
+                    // ... and what the filling above made of them (round 5: the row-form solver does not fill again)
+                    double* const ywrow = reinterpret_cast<double*>(&S.ws[wv]) + row * 64u;
+#pragma unroll
+                    for (int j = 0; j < kSlots; j++) ywrow[j * 16 + q] = 0.0;
+                    if (q == 0u) S.capv[wv][row] = (solve_me && fill) ? (int)cap_viol : 0;
+                    lds_sync();
+#pragma unroll
+                    for (int c = 0; c < NS; c++)
+                        if (solve_me && valid[c]) ywrow[st[c]] = y[c];
                     const unsigned rows = ((solve_mask & 0xffffull) ? 1u : 0u) | ((solve_mask & 0xffff0000ull) ? 2u : 0u) |
                                           ((solve_mask & 0xffff00000000ull) ? 4u : 0u) | ((solve_mask >> 48) ? 8u : 0u) |
                                           (KIND != 0 ? 16u : 0u) | (KIND == 0 ? (unsigned)(step + 1) << 8 : 0u);

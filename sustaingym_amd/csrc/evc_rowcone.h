@@ -374,7 +374,11 @@ __device__ __forceinline__ bool quad_cone_capped(int G, const double* class_cap,
 __device__ __forceinline__ bool quad_project(int G, const double* class_cap, unsigned simple_rows, unsigned long long* tie_counters, int tie_log2, const LdsNet& net,
                                              unsigned q, unsigned m, unsigned row, bool on, const int (&st_gid)[kSlots],
                                              const bool (&is_cc)[kSlots], const double (&b)[kSlots], const double (&h)[kSlots],
-                                             double (&y)[kSlots], double (*zw)[2] = nullptr, bool warm_ok = false, bool* stored = nullptr) {
+                                             double (&y)[kSlots], double (*zw)[2] = nullptr, bool warm_ok = false, bool* stored = nullptr,
+                                             const double* ywin = nullptr, unsigned capv_in = 0u, double tol_in = Consts::PROJ_TOL) {
+    // ywin / capv_in (round 5, row-uniform capv_in): the caller has ALREADY clipped to the box and filled the classes in capv_in
+    // (the period's body does, on the entries, before it decides that a row needs this call): ywin = that schedule (tie-snapped,
+    // hence tol_in = Params::snap_tol for its rows), and the exact rows at the box clip + the fillings are not repeated here.
     double y0[kSlots];
 #pragma unroll
     for (int j = 0; j < kSlots; j++) { y0[j] = fmin(b[j], h[j]); y[j] = y0[j]; }
@@ -403,7 +407,10 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
         }
     }
     const bool warm_row = warm1 || warm2;
-    const RowExact e0 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y0);
+    const bool handed = ywin != nullptr && on && !warm_row && capv_in != 0u;
+    RowExact e0{0u, 0u, -1};
+    if (__ballot(on && !warm_row && !handed) != 0ull) e0 = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, y0);
+    if (handed) { e0.viol = 1u; e0.cap_viol = capv_in; e0.worst = -1; }      // (which row: known after the rows of ywin below)
     bool settled = on && !warm_row && e0.viol == 0u && e0.cap_viol == 0u;
     bool open = on && !warm_row && !settled;
     bool d2 = false;                               // a pair of rows to solve together, from the filling or from the chain
@@ -414,12 +421,13 @@ __device__ __forceinline__ bool quad_project(int G, const double* class_cap, uns
     if (__ballot(fill) != 0ull) {
         double yw[kSlots];
 #pragma unroll
-        for (int j = 0; j < kSlots; j++) yw[j] = y0[j];
+        for (int j = 0; j < kSlots; j++) yw[j] = handed ? ywin[j] : y0[j];
         for (int g = 0; g < G; g++) {
-            const bool do_g = fill && ((e0.cap_viol >> g) & 1u);
+            const bool do_g = fill && !handed && ((e0.cap_viol >> g) & 1u);
             if (__ballot(do_g) != 0ull) quad_waterfill_bh(do_g, g, st_gid, b, h, class_cap[g], yw);
         }
-        const RowExact ew = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, yw);
+        const RowExact ew = quad_exact_rows_worst(G, class_cap, net, q, m, row, st_gid, yw, handed ? tol_in : Consts::PROJ_TOL);
+        if (handed) e0.worst = ew.worst;               // the chain below starts from the worst row it knows
         const bool okw = fill && ew.viol == 0u && ew.cap_viol == 0u;
         if (okw) {
 #pragma unroll
