@@ -125,7 +125,7 @@ struct evc_engine {
     // for the side streams at the next join (evc_join, or any other engine call — bind() joins).
     int pipeline = 1;
     hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr}, phase_ev = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
     bool halves_pending = false, side_warmed = false, last_split = false, side_ready = false;
     bool halves_exposed = false;  // evc_pipeline_half handed the side streams to the caller (closed loop per half)
     unsigned train_len = 0, prev_train_len = 0;   // pipelined steps since the last join, and in the train before it
@@ -198,7 +198,6 @@ void free_all(evc_engine* e) {
     for (auto& ev : e->roll.ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
-    if (e->phase_ev) (void)hipEventDestroy(e->phase_ev);
     for (int h = 0; h < 2; h++) {
         if (e->join_ev[h]) (void)hipEventDestroy(e->join_ev[h]);
         if (e->side[h]) (void)hipStreamDestroy(e->side[h]);
@@ -519,17 +518,9 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         // 27.9 -> 26.7 us per step with the skew on every cold start, 27.8 -> 28.3 with this rule; long runs unchanged.  No
         // reliable gain: off by default.
         static const int skew_us = getenv("EVC_PIPE_SKEW_US") ? atoi(getenv("EVC_PIPE_SKEW_US")) : kPipeSkewUs;
-        // Round 4 — the trains de-phased BY CONSTRUCTION.  In steady state the two trains run half a period apart (kernel trace
-        // of round 3: B's launches begin 0.49 - 0.52 of a period after A's, each launch lasting one period).  A train that starts
-        // from idle streams — after a join, or after the caller drained the device (torch.cuda.synchronize: what a timed
-        // window begins with) — would start both halves together.  So the first step of such a train runs half A as TWO
-        // quarter launches and lets half B wait for the first quarter: B begins when half of A's work is done, whatever the
-        // workload, at the price of one more prologue (~3 us, once per train).  Measured on the driver's window (20 steps after
-        // 5 warm-up steps and a device synchronisation, tools/ab_window.sh, 4 interleaved pairs): 25.6 / 25.6 / 27.3 / 25.5 us
-        // per step with it, 26.3 / 25.1 / 24.7 / 25.9 without — what the short window pays is not the lock-step start (the
-        // trains drift apart within three or four steps) but the drained GPU's first launches and the final drain; steady state
-        // 22.99 either way.  No gain: OFF by default, EVC_PIPE_PHASE=1 turns it on.
-        static const bool phase_on = getenv("EVC_PIPE_PHASE") && atoi(getenv("EVC_PIPE_PHASE")) != 0;
+        // (Round 4 also built a start that de-phases the trains BY CONSTRUCTION — half A's first launch as two quarter launches,
+        // half B behind the first: 25.6 / 25.6 / 27.3 / 25.5 us per step on the driver's window against 26.3 / 25.1 / 24.7 / 25.9
+        // without — no gain; the path was removed in round 5 (untested quarter grids against the drain list's capacity).)
         // "drained behind our back" is told by the host clock, not by querying the streams (two runtime calls per step, and a
         // host that is only just ahead of the GPU would find them idle again and again): a gap of more than 200 us since the
         // last pipelined step was issued is at least eight step times — the trains have run dry.
@@ -537,8 +528,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
         const double gap_us = std::chrono::duration<double, std::micro>(now - e->last_split_issue).count();
         e->last_split_issue = now;
         static const double gap_limit = getenv("EVC_PIPE_GAP_US") ? atof(getenv("EVC_PIPE_GAP_US")) : 200.0;
-        const bool cold = !e->halves_pending || ((phase_on || skew_us > 0) && gap_us > gap_limit);
-        const bool phased = cold && phase_on && !e->timing && mid >= 64;
+        const bool cold = !e->halves_pending || (skew_us > 0 && gap_us > gap_limit);
         if (cold) { e->prev_train_len = e->train_len; e->train_len = 0; }
         e->train_len++;
         for (int h = 0; h < 2; h++) {
@@ -559,21 +549,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 hipLaunchKernelGGL(skew_kernel, dim3(1), dim3(64), 0, e->side[h], (unsigned)skew_us * 100u);
             if (e->timing) {
                 hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, e->side[h], e->ev[h ? 4 : 0], e->ev[h ? 5 : 1], 0, Ph, ioh);
-            } else if (phased && h == 0) {
-                const int qmid = (mid / 2) & ~7;
-                StepIO q1 = ioh, q2 = ioh;
-                q1.quad_hi = qmid;
-                q2.quad_lo = qmid;
-                int g1 = (qmid + 3) / 4, g2 = (mid - qmid + 3) / 4;
-                if (g1 > split_cap) g1 = split_cap;
-                if (g2 > split_cap) g2 = split_cap;
-                if (g1 >= 8) g1 -= g1 % 8;
-                if (g2 >= 8) g2 -= g2 % 8;
-                hipLaunchKernelGGL(kernel, dim3(g1), dim3(256), 0, e->side[0], Ph, q1);
-                (void)hipEventRecord(e->phase_ev, e->side[0]);
-                hipLaunchKernelGGL(kernel, dim3(g2), dim3(256), 0, e->side[0], Ph, q2);
             } else {
-                if (phased && h == 1) (void)hipStreamWaitEvent(e->side[1], e->phase_ev, 0);
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, e->side[h], Ph, ioh);
             }
             if (with_slow) {
@@ -983,7 +959,6 @@ int evc_set_pipeline(evc_engine* e, int32_t halves) {
     if (halves == 2 && !e->side_ready) {
         // each object is created once: a call that failed half way is resumed, not skipped, by the next one
         if (!e->fork_ev) HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
-        if (!e->phase_ev) HIP_TRY(hipEventCreateWithFlags(&e->phase_ev, hipEventDisableTiming));
         for (int h = 0; h < 2; h++) {
             if (!e->join_ev[h]) HIP_TRY(hipEventCreateWithFlags(&e->join_ev[h], hipEventDisableTiming));
             if (!e->side[h]) HIP_TRY(hipStreamCreateWithFlags(&e->side[h], hipStreamNonBlocking));
