@@ -355,7 +355,10 @@ class EVChargingVectorEnv(_VectorEnvBase):
     hands out the engine's two alternating page-locked buffer sets (valid until the step after the next
     one; what SB3VecEnv, which copies anyway, and throughput measurements use).  ``'torch'`` takes and
     returns device tensors without leaving the GPU; those ARE the engine's output buffers and are
-    overwritten by the next step (clone what must be kept).
+    overwritten by the next step (clone what must be kept).  On that path the observation dict, the
+    ``reward_breakdown`` dict and — within an episode — the ``info`` dict are the SAME objects every step
+    (like the reference's reused observation buffers, env.py:152-158): a caller that stores or mutates them
+    sees them change; copy what must be kept.
 
     ``pipeline=2`` (``output='torch'`` only; opt-in, changes the ordering contract): float32 steps run as two
     half-batch launches on two internal streams (``evc_set_pipeline``) and ``step()`` does NOT order the caller's
