@@ -84,6 +84,7 @@ struct evc_engine {
     int* d_slow_count = nullptr;  // [2 halves][2]: queue length per step parity (second pair: the second half launch of the pipelined mode); [4..5]: always zero, for the warm-up launches
     int* d_slow_list = nullptr;
     unsigned long long* d_tie = nullptr;   // Params::tie_counters
+    char* h_act = nullptr;                 // page-locked staging block for pageable host actions (evc_step_host, direct mode)
     // Drain mode (who solves what the streaming kernel queues): on a workload whose steps queue at most a few
     // dozen environments every workgroup of the lean compact streaming kernel solves the ones it queued itself
     // and NO slow kernel is launched (saves the ~2 us an almost always empty dependent launch costs per step;
@@ -203,6 +204,7 @@ void free_all(evc_engine* e) {
         if (e->side[h]) (void)hipStreamDestroy(e->side[h]);
     }
     if (e->h_qlen) (void)hipHostFree(e->h_qlen);
+    if (e->h_act) (void)hipHostFree(e->h_act);
 }
 
 // Station classes: identical (constraint column, phase angle).  Every constraint depends on a
@@ -1301,6 +1303,40 @@ int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, 
     // enqueued behind the kernel and the call waits ONCE — the round-4 form synchronised after each of its six transfers
     // (~15 us of round trip each, of a 424 us step at 16 384 environments).  Pageable buffers go through the bounce copies.
     hipError_t hrc = hipSuccess;
+    // Round 5 — DIRECT mode (what SB3 / RLlib drive: tens to a few thousand environments, numpy in / numpy out): with page-locked
+    // output buffers the kernels read the actions from and write the outputs to HOST memory themselves, over PCIe: one launch
+    // and one synchronisation per step, no DMA engine in the loop (its start-up per copy, five copies per step, was most of a
+    // 66 us step at 256 environments).  profiles/r5_host_direct.txt, us per step copies -> direct: 64 envs 63 -> 35, 256: 82 -> 37,
+    // 1 024: 93 -> 54, 4 096: 164 -> 112, 16 384: 419 -> 355, 65 536: 1 228 -> 1 152.  EVC_HOST_DIRECT_MAX_BYTES (bytes of
+    // observations per step; 0 = never) restores the copies above a size.  No per-station debug outputs in this mode.
+    const long long direct_max = getenv("EVC_HOST_DIRECT_MAX_BYTES") ? atoll(getenv("EVC_HOST_DIRECT_MAX_BYTES")) : LLONG_MAX;
+    if ((long long)(N * F * 4) <= direct_max && !oh->pilots && !oh->rates && !oh->projected && oh->obs && oh->reward && oh->terminated &&
+        (action_kind == EVC_ACTION_F32 || action_kind == EVC_ACTION_DISCRETE || !actions_host)) {
+        void* da = actions_host ? HostCopier::device_view(actions_host) : nullptr;
+        if (actions_host && !da) {
+            // pageable actions (a fresh numpy array every step, as SB3 hands them over): through the engine's own page-locked
+            // staging block (a memcpy of N x n x 4 bytes) — the previous step has been waited for, the block is free
+            if (!e->h_act && hipHostMalloc((void**)&e->h_act, N * n * 8, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); e->h_act = nullptr; }
+            if (e->h_act) {
+                memcpy(e->h_act, actions_host, abytes);
+                da = HostCopier::device_view(e->h_act);
+            }
+        }
+        evc_step_out od{};
+        od.obs = (float*)HostCopier::device_view(oh->obs);
+        od.reward = (double*)HostCopier::device_view(oh->reward);
+        od.terminated = (uint8_t*)HostCopier::device_view(oh->terminated);
+        od.breakdown = oh->breakdown ? (double*)HostCopier::device_view(oh->breakdown) : nullptr;
+        od.final_obs = oh->final_obs ? (float*)HostCopier::device_view(oh->final_obs) : e->d_final;
+        const bool ok = (!actions_host || da) && od.obs && od.reward && od.terminated && (!oh->breakdown || od.breakdown) &&
+                        (!oh->final_obs || od.final_obs);
+        if (ok) {
+            if (int rc = launch_step(e, da, action_kind, bins, &od)) return rc;
+            if (int rc = join_halves(e)) return rc;
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            return EVC_OK;
+        }
+    }
     if (actions_host && !HostCopier::h2d_async(e->d_act, actions_host, abytes, e->stream, hrc))
         hrc = copy_h2d(e->d_act, actions_host, abytes, e->stream);
     HIP_TRY(hrc);

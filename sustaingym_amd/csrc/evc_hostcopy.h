@@ -96,6 +96,18 @@ public:
         return true;
     }
 
+    // The device-side address of page-locked host memory (hipHostRegister / hipHostMalloc), or nullptr: kernels can read and
+    // write it directly over PCIe (evc_step_host's direct mode for small batches).
+    static void* device_view(const void* host) {
+        if (!host || !is_pinned(host)) return nullptr;
+        void* dev = nullptr;
+        if (hipHostGetDevicePointer(&dev, const_cast<void*>(host), 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return dev;
+    }
+
     // One copier per DEVICE (the calling engine has made its device current): HIP events belong to the device that was
     // current when they were created and cannot be recorded on another device's stream, so a single process-wide set
     // would break the second engine of a process that drives two GPUs.  The buffers live until the process ends.

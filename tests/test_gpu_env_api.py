@@ -565,3 +565,41 @@ def test_torch_lean_path_info_max_profit_follows_the_episode():
     _, _, _, _, info = venv.step(act)
     assert np.array_equal(np.asarray(info['max_profit']), venv._max_profit[venv._cur_slot])
     venv.close()
+
+
+@pytest.mark.gpu
+def test_host_step_direct_mode_equals_the_copy_mode(monkeypatch):
+    """evc_step_host: the kernels writing the page-locked host buffers themselves (default) against the staged copies
+    (EVC_HOST_DIRECT_MAX_BYTES=0): every output of every step, pageable and discrete actions, across an episode boundary."""
+    from sustaingym_amd.engine import StepEngine
+    from sustaingym_amd.network import caltech_acn
+    from helpers import make_workload
+    net = caltech_acn()
+    N = 300
+    wl = make_workload(net, N, bank_slots=64, seed=23, busy=True, moer_days=3)
+    engines = []
+    for _ in range(2):
+        eng = StepEngine(net, N, project_action=True, autoreset=True, bank_slots=64, max_sessions=wl['sessions'].shape[1],
+                         moer_days=wl['moer'].shape[0])
+        eng.upload_moer(wl['moer'])
+        eng.upload_episodes(wl['n_sessions'], wl['sessions'], wl['requested'], wl['moer_day'])
+        eng.set_autoreset_stride(5)
+        engines.append(eng)
+    rng = np.random.default_rng(4)
+    assert np.array_equal(engines[0].reset(host=True), engines[1].reset(host=True))
+    for t in range(300):
+        if t % 3 == 2:
+            a, bins = rng.integers(0, 5, (N, net.num_stations)), 5
+        else:
+            a, bins = rng.random((N, net.num_stations), dtype=np.float32), 0
+        monkeypatch.delenv('EVC_HOST_DIRECT_MAX_BYTES', raising=False)
+        d = {k: np.array(v) for k, v in engines[0].step(a, bins=bins).items()}
+        monkeypatch.setenv('EVC_HOST_DIRECT_MAX_BYTES', '0')
+        c = {k: np.array(v) for k, v in engines[1].step(a, bins=bins).items()}
+        for key in ('obs', 'reward', 'terminated', 'breakdown'):
+            assert np.array_equal(d[key], c[key]), (t, key)
+        if d['terminated'].any():
+            assert np.array_equal(d['final_obs'], c['final_obs']), t
+    monkeypatch.delenv('EVC_HOST_DIRECT_MAX_BYTES', raising=False)
+    for eng in engines:
+        eng.close()
