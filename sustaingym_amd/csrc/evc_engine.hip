@@ -1308,9 +1308,9 @@ int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, 
     // and one synchronisation per step, no DMA engine in the loop (its start-up per copy, five copies per step, was most of a
     // 66 us step at 256 environments).  profiles/r5_host_direct.txt, us per step copies -> direct: 64 envs 63 -> 35, 256: 82 -> 37,
     // 1 024: 93 -> 54, 4 096: 164 -> 112, 16 384: 419 -> 355, 65 536: 1 228 -> 1 152.  EVC_HOST_DIRECT_MAX_BYTES (bytes of
-    // observations per step; 0 = never) restores the copies above a size.  No per-station debug outputs in this mode.
+    // observations per step; 0 = never) restores the copies above a size.
     const long long direct_max = getenv("EVC_HOST_DIRECT_MAX_BYTES") ? atoll(getenv("EVC_HOST_DIRECT_MAX_BYTES")) : LLONG_MAX;
-    if ((long long)(N * F * 4) <= direct_max && !oh->pilots && !oh->rates && !oh->projected && oh->obs && oh->reward && oh->terminated &&
+    if ((long long)(N * F * 4) <= direct_max && oh->obs && oh->reward && oh->terminated &&
         (action_kind == EVC_ACTION_F32 || action_kind == EVC_ACTION_DISCRETE || !actions_host)) {
         void* da = actions_host ? HostCopier::device_view(actions_host) : nullptr;
         if (actions_host && !da) {
@@ -1328,8 +1328,12 @@ int evc_step_host(evc_engine* e, const void* actions_host, int32_t action_kind, 
         od.terminated = (uint8_t*)HostCopier::device_view(oh->terminated);
         od.breakdown = oh->breakdown ? (double*)HostCopier::device_view(oh->breakdown) : nullptr;
         od.final_obs = oh->final_obs ? (float*)HostCopier::device_view(oh->final_obs) : e->d_final;
+        od.pilots = oh->pilots ? (double*)HostCopier::device_view(oh->pilots) : nullptr;
+        od.rates = oh->rates ? (double*)HostCopier::device_view(oh->rates) : nullptr;
+        od.projected = oh->projected ? (double*)HostCopier::device_view(oh->projected) : nullptr;
         const bool ok = (!actions_host || da) && od.obs && od.reward && od.terminated && (!oh->breakdown || od.breakdown) &&
-                        (!oh->final_obs || od.final_obs);
+                        (!oh->final_obs || od.final_obs) && (!oh->pilots || od.pilots) && (!oh->rates || od.rates) &&
+                        (!oh->projected || od.projected);
         if (ok) {
             if (int rc = launch_step(e, da, action_kind, bins, &od)) return rc;
             if (int rc = join_halves(e)) return rc;
