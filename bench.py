@@ -796,6 +796,38 @@ def secondary_sync_reference(site, dev_index, battery, project) -> dict:
                                 'note': "round 1's BENCH line (2.31e9) timed this window"}}
 
 
+def secondary_small_configs(dev_index, battery) -> dict:
+    """BASELINE configs[0] and configs[1]: ONE EVChargingEnv behind the Gymnasium API with DiscreteActionWrapper (host round trip
+    per step: evc_step_host's direct mode — the kernels write the page-locked numpy buffers themselves), and 4 096 batched
+    environments with continuous actions on the device path (launch-bound: one quad per wavefront)."""
+    import torch
+    from sustaingym_amd import DiscreteActionWrapper, EVChargingEnv, GMMsTraceGenerator
+    out = {}
+    env = DiscreteActionWrapper(EVChargingEnv(GMMsTraceGenerator('caltech', 'Summer 2021'), device=dev_index, charge_calculation=battery))
+    env.reset(seed=0)
+    acts = np.random.default_rng(0).integers(0, 5, (288, 54))
+    for t in range(32):
+        env.step(acts[t])
+    ts = []
+    for t in range(32, 288):
+        t0 = time.perf_counter()
+        env.step(acts[t])
+        ts.append(time.perf_counter() - t0)
+    env.close()
+    out['config0_single_env_gymnasium'] = {'workload': 'one EVChargingEnv (caltech, GMM day), DiscreteActionWrapper(bins=5), projection on, numpy in / dict of numpy out',
+                                           'us_per_step_median': round(float(np.median(ts)) * 1e6, 1), 'us_per_step_mean': round(float(np.mean(ts)) * 1e6, 1),
+                                           'env_steps_per_s': round(1.0 / float(np.median(ts)), 1), 'pcie_inclusive': True}
+    N = 4096
+    for project in (True, False):
+        w = EvWorkload('caltech', N, dev_index, 0, project=project, bank=1024, phase='stagger', battery=battery, pipeline=1)
+        w.run(64)
+        wall = w.wall_ms_per_step(2 * EPISODE)
+        w.close()
+        out[f'config1_4096_device_project{int(project)}'] = {'workload': f'{N} x 54-station (caltech), U[0,1) actions resident in HBM, project_action_in_env={project}, one launch per step',
+                                                              'ms_per_step': round(wall, 5), 'env_steps_per_s': round(N / wall * 1e3, 1)}
+    return out
+
+
 def secondary_multiagent(dev_index, battery) -> dict:
     """BASELINE configs[4]: 8 192 environments x 54 agents.  'view' = zero-copy [N, n, F] broadcast of the flat
     observation (what the reference's multiagent_env.py:114-117 hands out: the same array for every agent);
@@ -1120,6 +1152,7 @@ def main():
                          ('rollout_greedy_65536_jpl_gmm', lambda: secondary_rollout('greedy', local_rank, args.battery, 'gmm', 'jpl')),
                          ('closed_loop_65536', lambda: secondary_closed_loop(local_rank, args.battery)),
                          ('vector_env_api', lambda: secondary_vector_env_api(local_rank, args.battery)),
+                         ('small_configs', lambda: secondary_small_configs(local_rank, args.battery)),
                          ('rccl_world1', secondary_rccl_world1),
                          ('multiagent_8192x54', lambda: secondary_multiagent(local_rank, args.battery)),
                          ('battery_16384', lambda: secondary_battery(local_rank)),
