@@ -817,6 +817,24 @@ def secondary_small_configs(dev_index, battery) -> dict:
     out['config0_single_env_gymnasium'] = {'workload': 'one EVChargingEnv (caltech, GMM day), DiscreteActionWrapper(bins=5), projection on, numpy in / dict of numpy out',
                                            'us_per_step_median': round(float(np.median(ts)) * 1e6, 1), 'us_per_step_mean': round(float(np.mean(ts)) * 1e6, 1),
                                            'env_steps_per_s': round(1.0 / float(np.median(ts)), 1), 'pcie_inclusive': True}
+    # the stable_baselines3 VecEnv adapter itself (train_stable_baselines.py:271-275's SubprocVecEnv replaced): 4 096 environments,
+    # numpy in / numpy out + the per-environment info objects SB3 asks for
+    from sustaingym_amd.envs import EVChargingVectorEnv, SB3VecEnv
+    from sustaingym_amd.event_generation import DeviceGMMTraceGenerator
+    for mode, copy_obs in (('lazy', True), ('lazy', False), ('dicts', True)):
+        sb3 = SB3VecEnv(EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2021', seed=0), num_envs=4096, device=dev_index,
+                                            charge_calculation=battery), infos=mode, copy_obs=copy_obs)
+        sb3.reset()
+        a = np.random.default_rng(0).random((4096, 54), dtype=np.float32)
+        reps = 40 if mode == 'lazy' else 6
+        for _ in range(4):
+            sb3.step(a)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sb3.step(a)
+        dt = (time.perf_counter() - t0) / reps
+        sb3.close()
+        out[f'sb3_vecenv_4096_infos_{mode}' + ('' if copy_obs else '_zero_copy_obs')] = {'ms_per_step': round(dt * 1e3, 4), 'env_steps_per_s': round(4096 / dt, 1), 'pcie_inclusive': True}
     N = 4096
     for project in (True, False):
         w = EvWorkload('caltech', N, dev_index, 0, project=project, bank=1024, phase='stagger', battery=battery, pipeline=1)

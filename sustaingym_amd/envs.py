@@ -752,15 +752,101 @@ class MultiAgentEVChargingVectorEnv:
         self.venv.close()
 
 
+class _StepInfoSource:
+    """What the per-environment info dicts of one SB3VecEnv step are made of (arrays over the batch)."""
+    __slots__ = ('max_profit', 'breakdown', 'done', 'final')
+
+    def __init__(self):
+        self.max_profit = self.breakdown = self.done = self.final = None
+
+
+class _LazyInfo(dict):
+    """``infos[i]`` of :class:`SB3VecEnv` without a Python loop over the batch: a dict whose items are read out of the step's
+    batch arrays when somebody asks (SB3 itself looks at ``TimeLimit.truncated`` / ``terminal_observation`` of the environments
+    that ended; monitors ``.copy()`` and add an ``episode`` key).  The N objects are created once; every step they describe the
+    CURRENT step (keep ``dict(info)`` / ``info.copy()`` — real dicts — if an old one is needed).  Extra keys a wrapper stores
+    through ``info[k] = v`` live in the dict proper and stay with that environment's object."""
+    __slots__ = ('_src', '_i')
+    _KEYS = ('max_profit', 'reward_breakdown', 'TimeLimit.truncated')
+
+    def __init__(self, src: _StepInfoSource, i: int):
+        super().__init__()
+        self._src, self._i = src, i
+
+    def _has_terminal(self) -> bool:
+        return self._src.done is not None and bool(self._src.done[self._i])
+
+    def __missing__(self, key):
+        s, i = self._src, self._i
+        if key == 'max_profit':
+            return float(s.max_profit[i])
+        if key == 'reward_breakdown':
+            b = s.breakdown[i]
+            return {'profit': float(b[0]), 'carbon_cost': float(b[1]), 'excess_charge': float(b[2])}
+        if key == 'TimeLimit.truncated':
+            return False
+        if key == 'terminal_observation' and self._has_terminal():
+            return {k: v[i].copy() for k, v in s.final.items()}
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._KEYS or (key == 'terminal_observation' and self._has_terminal())
+
+    def keys(self):
+        ks = list(self._KEYS) + (['terminal_observation'] if self._has_terminal() else [])
+        return ks + [k for k in dict.keys(self) if k not in ks]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def copy(self):
+        return dict(self.items())
+
+    def __repr__(self):
+        return repr(self.copy())
+
+    def __eq__(self, other):
+        return self.copy() == (other.copy() if isinstance(other, _LazyInfo) else other)
+
+    __hash__ = None
+
+
 class SB3VecEnv(_SB3VecEnvBase):
     """stable_baselines3 ``VecEnv`` protocol over :class:`EVChargingVectorEnv`
     (used like train_stable_baselines.py:275 uses SubprocVecEnv; policy ``MultiInputPolicy``).
     Derives from SB3's ``VecEnv`` when stable_baselines3 is installed, so that algorithms take it as
-    it is instead of wrapping it in a DummyVecEnv."""
+    it is instead of wrapping it in a DummyVecEnv.
 
-    def __init__(self, venv: EVChargingVectorEnv):
+    ``infos='lazy'`` (default): ``step_wait`` returns a list of N dict objects that read their items out of the step's batch
+    arrays on access (:class:`_LazyInfo`) — building N real dicts cost 1.5 us per environment per step in Python, 6 ms at 4 096
+    environments against an engine step of 0.11 ms.  ``infos='dicts'`` builds real dicts like DummyVecEnv does."""
+
+    def __init__(self, venv: EVChargingVectorEnv, infos: str = 'lazy', copy_obs: bool = True):
         assert venv.output == 'numpy'
+        assert infos in ('lazy', 'dicts')
         self.venv = venv
+        self._infos_mode = infos
+        # copy_obs=False hands out the engine's two alternating page-locked observation buffers themselves: what step k returns
+        # stays valid until step k + 2 is taken — enough for SB3's own collect loops (they turn step k's observation into
+        # step k + 1's action and COPY it into their rollout / replay buffer), not for a wrapper that keeps older observations
+        self._copy_obs = bool(copy_obs)
+        self._info_src = _StepInfoSource()
+        self._lazy: list[_LazyInfo] | None = None
         # this adapter copies every array it hands out (SB3's rollout buffer keeps references across steps), so on ITS
         # calls the vector env underneath may hand out its alternating page-locked buffers instead of copying a first
         # time (step_wait); the caller's venv object itself is left as it was configured
@@ -793,6 +879,19 @@ class SB3VecEnv(_SB3VecEnvBase):
             obs, rew, term, trunc, info = self.venv.step(self._actions)
         finally:
             self.venv.zero_copy = keep
+        if self._infos_mode == 'lazy':
+            src = self._info_src
+            src.max_profit = info['max_profit']
+            bd = info['reward_breakdown']
+            src.breakdown = np.stack([bd['profit'], bd['carbon_cost'], bd['excess_charge']], axis=1)     # a copy: [N, 3]
+            if term.any():
+                src.done = np.array(term, dtype=bool)
+                src.final = {k: v.copy() for k, v in info['final_observation'].items()}
+            else:
+                src.done = src.final = None
+            if self._lazy is None:
+                self._lazy = [_LazyInfo(src, i) for i in range(self.num_envs)]
+            return ({k: v.copy() for k, v in obs.items()} if self._copy_obs else dict(obs)), rew.astype(np.float32), term, self._lazy
         infos: list[dict[str, Any]] = []
         bd = info['reward_breakdown']
         for i in range(self.num_envs):

@@ -603,3 +603,35 @@ def test_host_step_direct_mode_equals_the_copy_mode(monkeypatch):
     monkeypatch.delenv('EVC_HOST_DIRECT_MAX_BYTES', raising=False)
     for eng in engines:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_sb3_lazy_infos_equal_real_dicts():
+    """SB3VecEnv(infos='lazy'): the per-environment info objects read the step's batch arrays on access; item for item they
+    equal the real dicts of infos='dicts' — within an episode, at its end (terminal_observation) and after it."""
+    from sustaingym_amd.event_generation import DeviceGMMTraceGenerator
+    N = 96
+    envs = [SB3VecEnv(EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2019', seed=6), num_envs=N), infos=mode)
+            for mode in ('lazy', 'dicts')]
+    for e in envs:
+        e.seed(3)
+    obs = [e.reset() for e in envs]
+    rng = np.random.default_rng(8)
+    for t in range(1, 292):
+        a = rng.random((N, 54), dtype=np.float32)
+        (o1, r1, d1, i1), (o2, r2, d2, i2) = (e.step(a) for e in envs)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2)
+        if t in (1, 150, 288, 289):
+            assert len(i1) == N and isinstance(i1[0], dict)
+            for k in (0, 17, N - 1):
+                lazy, real = i1[k], i2[k]
+                assert sorted(lazy.keys()) == sorted(real.keys()) and ('terminal_observation' in lazy) == (t == 288)
+                assert lazy['max_profit'] == real['max_profit'] and lazy['reward_breakdown'] == real['reward_breakdown']
+                assert lazy.get('TimeLimit.truncated', True) is False and lazy.get('episode') is None
+                if t == 288:
+                    for key, val in real['terminal_observation'].items():
+                        assert np.array_equal(lazy['terminal_observation'][key], val)
+                c = lazy.copy()
+                assert type(c) is dict and c['max_profit'] == real['max_profit']
+    for e in envs:
+        e.close()
