@@ -47,6 +47,100 @@ def algorithmic_bytes_per_env_step(n: int, k: int) -> int:
     return 4 * n + 12 * n * 2 + 32 + (k + 1) * 4 + (2 * n + k + 2) * 4 + 33
 
 
+def layout_floor_bytes_per_env_step(n: int, k: int, mean_entries: float) -> float:
+    """What the COMPACT layout cannot avoid moving per env-step: the action row in (4n), the observation row out
+    (4(2n+k+2)), reward / done / breakdown out (33), the two 16-byte scalar records in and out (64), and the plugged-in EVs'
+    entries (float64 remaining demand + 4-byte entry word = 12 B) read and written back: 24 per entry.  The MOER row and the
+    arriving session record are shared / L2-resident and not counted.  A floor: a rate computed on it cannot exceed the HBM rate
+    by accounting alone (the SURVEY figure above counts 1 296 B of station-shaped state this layout never touches)."""
+    return 4 * n + 4 * (2 * n + k + 2) + 33 + 64 + 24.0 * mean_entries
+
+
+HEADLINE_MAX_BYTES = 4096       # the driver keeps a bounded tail of stdout: round 5's 20 KB line did not parse (VERDICT r5)
+
+
+def _pick(d, keys):
+    return {k2: d[k2] for k2 in keys if isinstance(d, dict) and k2 in d and d[k2] is not None}
+
+
+def headline_line(full: dict, full_path: str | None) -> dict:
+    """The ONE stdout line of the contract, cut down from the full record to what the driver and the judge read first: metric,
+    value, window, config, `roofline`, `cpu_baseline` and a handful of scalars.  Everything else (`secondary`, `per_rank`,
+    `episode_metrics`, notes) is in the file `full_record` names and on stderr.  Never more than HEADLINE_MAX_BYTES."""
+    cfg = full.get('config') or {}
+    roof = full.get('roofline') or {}
+    cpu = full.get('cpu_baseline') or {}
+    line = _pick(full, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling'))
+    line['vs_baseline'] = full.get('vs_baseline')
+    line.update(_pick(full, ('dtype', 'data')))
+    line['config'] = _pick(cfg, ('workload', 'envs_per_gpu', 'global_envs', 'parallelism', 'launches_per_step'))
+    line.update(_pick(full, ('ranks_seen', 'env_steps_timed')))
+    if full.get('n_gpus', 1) > 1:
+        line['per_rank_value'] = (full.get('per_rank') or {}).get('value')
+        if full.get('strong_scaling'):
+            line['strong_scaling'] = _pick(full['strong_scaling'], ('global_envs', 'ms_per_step', 'value'))
+    r = _pick(roof, ('bound', 'kernel', 'frac_hbm', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'window', 'frac_steady',
+                     'frac_survey', 'frac_survey_steady', 'frac_hbm_timed_window', 'algorithmic_bytes_per_env_step',
+                     'survey_bytes_per_env_step', 'mean_entries_per_env', 'avg_kernel_ms', 'step_period_ms', 'launches_per_step',
+                     'traffic_over_algorithmic'))
+    if roof:
+        r.setdefault('traffic', roof.get('traffic'))
+        if isinstance(roof.get('single_launch'), dict):
+            r['single_launch'] = _pick(roof['single_launch'], ('ms_per_step', 'avg_kernel_ms', 'frac', 'frac_survey'))
+        line['roofline'] = r
+    else:
+        line['roofline'] = None
+    line['cpu_baseline'] = _pick(cpu, ('value', 'unit', 'cores', 'kind', 'sample', 'single_thread_value')) or None
+    sec = full.get('secondary') or {}
+    scal = {}
+    for key in ('gmm_caltech', 'gmm_jpl', 'real_caltech'):
+        if isinstance(sec.get(key), dict) and 'ms_per_step' in sec[key]:
+            scal[key + '_us_per_step'] = round(sec[key]['ms_per_step'] * 1e3, 2)
+    for key in ('rollout_greedy_65536_gmm', 'rollout_random_65536_gmm'):
+        if isinstance(sec.get(key), dict) and 'env_steps_per_s' in sec[key]:
+            scal[key + '_env_steps_per_s'] = sec[key]['env_steps_per_s']
+    va = sec.get('vector_env_api') or {}
+    for key in ('torch', 'torch_pipeline2', 'torch_policy_greedy'):
+        if isinstance(va.get(key), dict) and 'ms_per_step' in va[key]:
+            scal['vector_env_' + key + '_us_per_step'] = round(va[key]['ms_per_step'] * 1e3, 2)
+    if scal:
+        line['secondary_scalars'] = scal
+    line['full_record'] = full_path
+    # belt and braces: whatever a future edit adds, the line stays inside the budget
+    for drop in ('secondary_scalars', 'per_rank_value', 'strong_scaling'):
+        if len(json.dumps(line)) <= HEADLINE_MAX_BYTES:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) > HEADLINE_MAX_BYTES:
+        line['config'] = _pick(line['config'], ('envs_per_gpu', 'global_envs', 'parallelism'))
+        line['config']['workload'] = str(cfg.get('workload', ''))[:200]
+        if line.get('cpu_baseline'):
+            line['cpu_baseline']['sample'] = str(line['cpu_baseline'].get('sample', ''))[:120]
+    assert len(json.dumps(line)) <= HEADLINE_MAX_BYTES
+    return line
+
+
+def emit(full: dict, out_path: str | None) -> str:
+    """Writes the full record to `out_path` (and, prefixed so that no line-oriented parser takes it for the headline, to stderr),
+    then prints the compact headline as the LAST and ONLY stdout line.  Returns that line."""
+    text = json.dumps(full)
+    written = None
+    if out_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+            with open(out_path, 'w') as fh:
+                fh.write(text + '\n')
+            written = os.path.relpath(out_path, ROOT) if os.path.abspath(out_path).startswith(ROOT) else out_path
+        except OSError as exc:
+            sys.stderr.write(f'bench.py: could not write {out_path}: {exc}\n')
+    sys.stderr.write('bench.py full record: ' + text + '\n')
+    sys.stderr.flush()
+    line = json.dumps(headline_line(full, written))
+    sys.stdout.write(line + '\n')
+    sys.stdout.flush()
+    return line
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -93,6 +187,8 @@ def parse_args(argv=None):
     p.add_argument('--secondary-budget-s', type=float, default=240.0, help='time box of all secondary records together')
     p.add_argument('--cpu-envs', type=int, default=8192)
     p.add_argument('--cpu-steps', type=int, default=96, help='minimum timed steps of the cpu_baseline sample')
+    p.add_argument('--full-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_full.json'),
+                   help="file that receives the full record (secondary legs, per-rank data, notes); the stdout line names it; '' = none")
     p.add_argument('--kernel-timing-steps', type=int, default=288,
                    help='launches timed one by one (HIP events on the engine stream) for the roofline leg')
     return p.parse_args(argv)
@@ -117,9 +213,12 @@ def spawn_ranks(n: int) -> int:
     if any(rcs):
         sys.stderr.write(f'bench.py: ranks exited with {rcs}\n')
         return 1
+    last = None
     for ln in out0.splitlines():            # the process-group backend may chat on stdout; the contract is ONE JSON line
         if ln.startswith('{') and ln.rstrip().endswith('}'):
-            sys.stdout.write(ln + '\n')
+            last = ln
+    if last is not None:
+        sys.stdout.write(last + '\n')
     return 0
 
 
@@ -308,45 +407,75 @@ def lookup_traffic(site, N, project, layout, launches_per_step=1):
         return None, None
 
 
-def roofline_record(w: EvWorkload, timed: dict, bytes_per_env_step: int) -> dict:
+def roofline_record(w: EvWorkload, timed: dict, survey_bytes_per_env_step: int, window_ms: float | None = None,
+                    mean_entries: float | None = None) -> dict:
+    """The streaming kernel against the 8 TB/s HBM peak, per STEP of w.N environments, in three accountings:
+
+    `frac_hbm`    what the PMC counters say moved (profiles/traffic.json, tied to this code object) over the steady step
+                  period — the bandwidth utilisation;
+    `frac`        ALGORITHMIC bytes over the same window `ms_per_step` is timed in.  Algorithmic = what the compact layout
+                  cannot avoid moving (layout_floor_bytes_per_env_step; round 6): a lower bound on the bytes, so
+                  `frac` cannot pass 1 by accounting alone and `traffic / algorithmic` >= 1 shows the re-reads;
+    `frac_survey` SURVEY §8(d)'s station-shaped 2 309 B per env-step on that window, the `frac` of rounds 1-5, kept for
+                  continuity: it counts 1 296 B of station-shaped state this layout never touches — a throughput index
+                  (env-steps/s x 2 309 B / 8 TB/s), not a bandwidth."""
     layout = os.environ.get('EVC_LAYOUT', 'compact')          # engine default (DESIGN.md §3)
     pipelined = timed.get('period_ms') is not None
     # one launch per step: the launch's own duration.  Pipelined halves: the period of the launch train (a step's two
     # launches overlap the neighbouring steps', so a launch's own duration is not what the GPU needs per step)
     avg = float(timed['period_ms'].mean()) if pipelined else float(timed['main_ms'].mean())
-    alg = bytes_per_env_step * w.N
-    achieved = alg / (avg * 1e-3) / 1e9
+    window = avg if window_ms is None else window_ms
+    survey = survey_bytes_per_env_step * w.N
+    floor_b = layout_floor_bytes_per_env_step(w.n, w.k, mean_entries) if (mean_entries is not None and layout == 'compact') \
+        else float(survey_bytes_per_env_step)
+    alg = floor_b * w.N
+
+    def frac(nbytes, ms):
+        return round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     traffic, source = lookup_traffic(w.site, w.N, w.project, layout, 2 if pipelined else 1)
     rec = {'bound': 'hbm', 'kernel': 'evc::step_kernel_cquad' if layout == 'compact' else 'evc::step_kernel_quad',
-           'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
+           'frac_hbm': frac(traffic, avg) if traffic else None,
+           'achieved': round(alg / (window * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': frac(alg, window),
            'traffic': traffic,
-           # what the kernel really moves (the compact state layout needs fewer bytes than the station-shaped
-           # algorithmic accounting): rate and fraction of peak on the MEASURED bytes
+           'window': ('achieved / frac / frac_survey: the timed region of ms_per_step' if window_ms is not None
+                      else 'achieved / frac / frac_survey: steady step period') + '; frac_hbm / frac_steady: steady step period (HIP events)',
+           'frac_steady': frac(alg, avg),
+           'frac_survey': frac(survey, window), 'frac_survey_steady': frac(survey, avg),
+           'frac_hbm_timed_window': frac(traffic, window) if traffic else None,
+           'algorithmic_bytes_per_env_step': round(floor_b, 1), 'survey_bytes_per_env_step': survey_bytes_per_env_step,
+           'mean_entries_per_env': None if mean_entries is None else round(mean_entries, 3),
            'traffic_gbs': round(traffic / (avg * 1e-3) / 1e9, 2) if traffic else None,
-           'frac_traffic': round(traffic / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
            'traffic_over_algorithmic': round(traffic / alg, 4) if traffic else None,
+           'traffic_over_survey': round(traffic / survey, 4) if traffic else None,
            'traffic_source': source,
            'state_layout': layout, 'avg_kernel_ms': round(avg, 5),
            'kernel_ms_min_max': [round(float(timed['main_ms'].min()), 5), round(float(timed['main_ms'].max()), 5)],
            'kernel_launches_timed': int(len(timed['main_ms'])),
            'solver_kernel_ms': round(float(timed['slow_ms'].mean()), 5),
            'slow_queue_envs_per_step': round(timed['slow_envs'], 1),
-           'algorithmic_bytes_per_launch': alg}
+           'algorithmic_bytes_per_launch': int(alg)}
     if pipelined:
         h = timed['half_ms']
         rec.update({
-            'launches_per_step': 2, 'algorithmic_bytes_per_launch': alg // 2, 'algorithmic_bytes_per_step': alg,
-            'basis': 'achieved = algorithmic bytes per STEP / step period.  A step is two half-batch launches on two streams '
-                     '(evc_set_pipeline) that overlap the neighbouring steps\' launches; step_period_ms = HIP events on the joining '
-                     'stream over windows of 288 steps; half_launch_ms = one launch\'s own begin-to-end time under that overlap '
-                     '(hipExtLaunchKernel events; what a kernel trace reports per dispatch); step_alone_ms = first begin to last end '
-                     'of a step issued alone',
+            'launches_per_step': 2, 'algorithmic_bytes_per_launch': int(alg) // 2, 'algorithmic_bytes_per_step': int(alg),
+            'basis': 'A step is two half-batch launches on two streams (evc_set_pipeline) that overlap the neighbouring steps\' '
+                     'launches; step_period_ms = HIP events on the joining stream over windows of 288 steps; half_launch_ms = one '
+                     'launch\'s own begin-to-end time under that overlap (hipExtLaunchKernel events; what a kernel trace reports '
+                     'per dispatch); step_alone_ms = first begin to last end of a step issued alone',
             'step_period_ms': round(avg, 5), 'avg_kernel_ms': round(float(h.mean()), 5),
             'kernel_ms_min_max': [round(float(h.min()), 5), round(float(h.max()), 5)], 'kernel_launches_timed': int(len(h)),
             'half_launch_ms': round(float(h.mean()), 5),
             'step_alone_ms': round(float(timed['main_ms'].mean()), 5),
             'step_period_ms_min_max': [round(float(timed['period_ms'].min()), 5), round(float(timed['period_ms'].max()), 5)]})
     return rec
+
+
+def mean_entries_per_env(w: EvWorkload) -> float:
+    """Plugged-in EVs per environment right now, from the step's own observation rows (demands > 0, env.py:381-394): the Ā of
+    layout_floor_bytes_per_env_step.  With staggered phases every period of the day is present, so this is the day's average."""
+    w.eng.join()
+    w.torch.cuda.synchronize(w.dev)
+    return float((w.out['obs'][:, :w.n] > 0).sum(dim=1).double().mean().item())
 
 
 def cpu_baseline_record(args, w: EvWorkload, acts) -> dict:
@@ -406,7 +535,10 @@ def secondary_days(site, episodes, dev_index, battery) -> dict:
     w.eng.set_pipeline(1)                            # the same day as one launch per step, and its kernels by time of day
     wall1 = w.wall_ms_per_step(EPISODE)
     timed = w.time_kernels(EPISODE)
-    alg = algorithmic_bytes_per_env_step(w.n, w.k)
+    # plugged-in EVs per environment, averaged over the day (24 samples of one more day): the A of the layout's byte floor
+    abar = float(np.mean([(w.run(12), mean_entries_per_env(w))[1] for _ in range(EPISODE // 12)]))
+    survey = algorithmic_bytes_per_env_step(w.n, w.k)
+    alg = layout_floor_bytes_per_env_step(w.n, w.k, abar)
     what = 'device-generated GMM days' if episodes == 'gmm' else f'the {w.P} ACN-Data days of Summer 2021 (RealTraceBank), real MOER'
     rec = {'workload': f'65536 x {w.n}-station ({site}) on {what}, projection on, U[0,1) actions, synchronised episodes, mean over one whole day',
            'ms_per_step': round(wall, 5), 'env_steps_per_s': round(65536 / wall * 1e3, 1),
@@ -418,10 +550,13 @@ def secondary_days(site, episodes, dev_index, battery) -> dict:
            'solver_kernel_us': round(float(timed['slow_ms'].mean()) * 1e3, 2),
            'solver_kernel_us_by_4h': [round(float(x.mean()) * 1e3, 1) for x in np.array_split(timed['slow_ms'], 6)],
            'slow_queue_envs_per_step': round(timed['slow_envs'], 1),
-           'roofline': {'bound': 'hbm', 'algorithmic_bytes_per_env_step': alg,
+           'roofline': {'bound': 'hbm', 'algorithmic_bytes_per_env_step': round(alg, 1), 'mean_entries_per_env': round(abar, 3),
+                        'survey_bytes_per_env_step': survey,
                         'achieved': round(alg * 65536 / (wall * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(alg * 65536 / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        'note': 'on the whole step (streaming + slow kernel), not on one kernel'}}
+                        'frac_survey': round(survey * 65536 / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        'note': 'on the whole step (streaming + slow kernel), not on one kernel; algorithmic = the compact layout\'s '
+                                'byte floor (layout_floor_bytes_per_env_step), frac_survey = the station-shaped SURVEY 8d figure of rounds 1-5'}}
     w.close()
     return rec
 
@@ -1115,25 +1250,26 @@ def main():
 
     roofline = cpu_baseline = episode_generation = secondary = None
     if rank == 0:
+        abar = mean_entries_per_env(w)
+        window_ms = elapsed / args.steps * 1e3
         timed = w.time_kernels(args.kernel_timing_steps)
-        roofline = roofline_record(w, timed, algorithmic_bytes_per_env_step(n, k))
-        roofline['launch_overhead_ms'] = round(elapsed / args.steps * 1e3 - roofline.get('step_period_ms', roofline['avg_kernel_ms']), 5)
-        # the same accounting on the window the driver's clock brackets (`ms_per_step`): `frac` above comes from separate
-        # windows measured after it (steady trains, HIP events); this one includes the window's cold start and final drain
-        alg_step = algorithmic_bytes_per_env_step(n, k) * N
-        roofline['frac_timed_window'] = round(alg_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)
-        if roofline.get('traffic'):
-            roofline['frac_traffic_timed_window'] = round(roofline['traffic'] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)
+        alg_b = algorithmic_bytes_per_env_step(n, k)
+        # `frac` / `achieved`: on the window `ms_per_step` is timed in (cold start of the two launch trains and the final drain
+        # included); `frac_steady`, `frac_hbm`, `frac_floor`: on the steady step period measured after it with HIP events
+        roofline = roofline_record(w, timed, alg_b, window_ms, abar)
+        roofline['launch_overhead_ms'] = round(window_ms - roofline.get('step_period_ms', roofline['avg_kernel_ms']), 5)
         if w.pipeline == 2 and not args.no_single_launch:
             # the same workload as ONE launch per step (evc_set_pipeline(1)), for continuity with rounds 1-2
             w.eng.set_pipeline(1)
             w.run(32)
             single_ms = w.wall_ms_per_step(max(args.steps, 288))
             t1 = w.time_kernels(args.kernel_timing_steps)
+            k_ms = float(t1['main_ms'].mean())
+            floor_b = roofline['algorithmic_bytes_per_env_step']
             roofline['single_launch'] = {'ms_per_step': round(single_ms, 5), 'env_steps_per_s': round(N / single_ms * 1e3, 1),
-                                         'avg_kernel_ms': round(float(t1['main_ms'].mean()), 5),
-                                         'frac': round(roofline['algorithmic_bytes_per_step' if 'algorithmic_bytes_per_step' in roofline
-                                                                else 'algorithmic_bytes_per_launch'] / (float(t1['main_ms'].mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                                         'avg_kernel_ms': round(k_ms, 5),
+                                         'frac': round(floor_b * N / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                         'frac_survey': round(alg_b * N / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
             w.eng.set_pipeline(2)
     if rank == 0:
         # Reset-path row: refill the whole episode bank with the on-device GMM generator
@@ -1201,6 +1337,7 @@ def main():
                        'phase': args.phase,
                        'pipeline': ('2 half-batch launches per step on 2 streams (evc_set_pipeline): all outputs of every step written, '
                                     'the halves\' launches overlap across steps' if w.pipeline == 2 else '1 launch per step'),
+                       'launches_per_step': 2 if w.pipeline == 2 else 1,
                        'pipelined_steps_timed': int(pipelined_timed)},
             # proof that `world` ranks stepped: gathered over the process group
             'ranks_seen': int(per_rank.shape[0]),
@@ -1233,7 +1370,7 @@ def main():
                                 'slow_path_moved_values': float(tie['solver_moved_values'])},
             'secondary': secondary,
         }
-        print(json.dumps(line))
+        emit(line, args.full_out or None)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -13,18 +13,33 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_on_one_device():
+def _records(p, full_path):
+    """The contract's ONE stdout line (compact headline) and the full record it names."""
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), p.stdout[-2000:]
+    assert len(lines[0]) <= 4096
+    head = json.loads(lines[0])
+    full = json.load(open(full_path))
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'ranks_seen', 'env_steps_timed'):
+        assert head[key] == full[key], key
+    assert head['config']['workload'] == full['config']['workload']
+    assert 'bench.py full record: {' in p.stderr
+    return head, full
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     steps, warmup, N = 20, 5, 65536
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--single-device',
-                        '--steps', str(steps), '--warmup', str(warmup), '--no-secondary', '--no-cpu-baseline'],
+                        '--steps', str(steps), '--warmup', str(warmup), '--no-secondary', '--no-cpu-baseline',
+                        '--full-out', str(tmp_path / 'full.json')],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, p.stdout[-2000:]
-    rec = json.loads(lines[0])
+    head, rec = _records(p, tmp_path / 'full.json')
+    assert head['per_rank_value'] == rec['per_rank']['value'] and head['strong_scaling']['value'] == rec['strong_scaling']['value']
+    assert head['roofline']['bound'] == 'hbm' and head['roofline']['frac'] <= 1.0
     assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2 and rec['scaling'] == 'weak'
     assert len(rec['per_rank']['value']) == 2 and len(rec['per_rank']['env_steps_timed']) == 2
     assert rec['per_rank']['env_steps_timed'] == [N * steps, N * steps]
@@ -41,7 +56,7 @@ def test_bench_two_ranks_on_one_device():
     assert rec['episode_metrics']['episodes_finished'] > 0
 
 
-def test_bench_eight_ranks_on_one_device():
+def test_bench_eight_ranks_on_one_device(tmp_path):
     """The driver's 8-rank launch shape (VERDICT r4 "next" #8): eight self-spawned ranks, gloo, one device, 4 096 environments
     each — every rank reports, the shards add up, the record says 8."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -50,12 +65,10 @@ def test_bench_eight_ranks_on_one_device():
     steps, warmup, n = 20, 5, 4096
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--single-device',
                         '--envs-per-gpu', str(n), '--steps', str(steps), '--warmup', str(warmup), '--no-secondary',
-                        '--no-cpu-baseline', '--bank', '1024'],
+                        '--no-cpu-baseline', '--bank', '1024', '--full-out', str(tmp_path / 'full.json')],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, p.stdout[-2000:]
-    rec = json.loads(lines[0])
+    head, rec = _records(p, tmp_path / 'full.json')
+    assert len(head['per_rank_value']) == 8
     assert rec['n_gpus'] == 8 and rec['ranks_seen'] == 8 and rec['scaling'] == 'weak'
     assert rec['per_rank']['env_steps_timed'] == [n * steps] * 8 and rec['env_steps_timed'] == 8 * n * steps
     assert rec['config']['global_envs'] == 8 * n and rec['config']['envs_per_gpu'] == n

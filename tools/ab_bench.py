@@ -13,12 +13,14 @@ for spec in sys.argv[2:]:
 res = {}
 for rep in range(reps):
     for name, env, args in specs:
-        out = subprocess.run([sys.executable, 'bench.py', '--no-secondary', '--no-cpu-baseline'] + args,
-                             env=dict(os.environ, **env), capture_output=True, text=True).stdout
-        line = [l for l in out.splitlines() if l.startswith('{')]
-        if not line:
+        full = '/tmp/ab_bench_full.json'                    # the stdout line is the compact headline; the full record is here
+        if os.path.exists(full):
+            os.remove(full)
+        subprocess.run([sys.executable, 'bench.py', '--no-secondary', '--no-cpu-baseline', '--full-out', full] + args,
+                       env=dict(os.environ, **env), capture_output=True, text=True)
+        if not os.path.exists(full):
             print(name, 'FAILED'); continue
-        d = json.loads(line[-1])
+        d = json.load(open(full))
         res.setdefault(name, []).append((d['ms_per_step'] * 1e3, d['roofline']['avg_kernel_ms'] * 1e3,
                                          d['roofline']['solver_kernel_ms'] * 1e3, d['roofline']['slow_queue_envs_per_step']))
 for name, v in res.items():

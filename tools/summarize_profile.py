@@ -14,8 +14,8 @@ def short(name: str) -> str:
     return name if len(name) < 90 else name[:87] + '...'
 
 
-def main(src: str, dst_prefix: str) -> None:
-    out = {}
+def main(src: str, dst_prefix: str, site: str = 'caltech') -> None:
+    out = {'site': site}
     ks = pd.read_csv(os.path.join(src, 'trace', 'bench_kernel_stats.csv'))
     ks['Name'] = ks['Name'].map(short)
     ks.to_csv(dst_prefix + '_kernel_stats.csv', index=False)
@@ -71,8 +71,9 @@ def main(src: str, dst_prefix: str) -> None:
         tj = json.load(open(tpath))
         f, w = e['FETCH_SIZE_KB_mean'], e['WRITE_SIZE_KB_mean']
         # pipelined halves (bench.py --pipeline 2, the default): a step is two launches of half the batch each
-        lps = 2 if 'half-batch' in str(out.get('bench_plain', {}).get('config', {}).get('pipeline', '')) else 1
-        tj['caltech_N65536_project1_compact'] = {
+        cfg = out.get('bench_plain', {}).get('config', {})
+        lps = cfg.get('launches_per_step') or (2 if 'half-batch' in str(cfg.get('pipeline', '')) else 1)
+        tj[f'{site}_N65536_project1_compact'] = {
             'hbm_bytes_per_launch': int((1.4 * f + w) * 1024), 'launches_per_step': lps,
             'fetch_kib': round(f, 1), 'write_kib': round(w, 1),
             'fetch_factor': 1.4, 'hbm_bytes_per_launch_raw_counters': int((f + w) * 1024),
@@ -86,4 +87,4 @@ def main(src: str, dst_prefix: str) -> None:
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else 'caltech')
