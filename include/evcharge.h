@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EVC_ABI_VERSION 6
+#define EVC_ABI_VERSION 7
 
 #define EVC_MAX_STATIONS     64   /* one gfx950 wavefront per environment            */
 #define EVC_MAX_CONSTRAINTS  32   /* rows of ChargingNetwork.constraint_matrix       */
@@ -317,6 +317,14 @@ int evc_get_station_state(evc_engine* e, double* remaining_kwh, int16_t* departu
                           int16_t* est_departure);
 int evc_set_station_state(evc_engine* e, const double* remaining_kwh, const int16_t* departure,
                           const int16_t* est_departure);
+/* ABI 7.  The compact layout keeps the plugged-in EVs of an environment as a LIST and the streaming
+ * kernel sums the delivered amps of env.py:445 in list order, so the last bit of a reward depends on that order (the
+ * history of plug-ins).  entry_rank [N][n] int16: position of the station's EV in its environment's list, -1 = EVSE
+ * empty (dense layout: the station index where occupied).  evc_set_station_state_ranked rebuilds the lists in that
+ * order (entry_rank == NULL: station order, = evc_set_station_state), so a checkpoint replays bit for bit. */
+int evc_get_entry_rank(evc_engine* e, int16_t* entry_rank);
+int evc_set_station_state_ranked(evc_engine* e, const double* remaining_kwh, const int16_t* departure,
+                                 const int16_t* est_departure, const int16_t* entry_rank);
 int evc_set_env_scalars(evc_engine* e, const int32_t* in_host);
 int evc_get_breakdown(evc_engine* e, double* out_host /* [N][3] */);
 int evc_set_breakdown(evc_engine* e, const double* in_host);

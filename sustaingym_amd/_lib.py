@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SUSTAINGYM_AMD_LIB', os.path.join(_PKG, 'libevcharge_hip.so'))
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'evcharge.h')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_STATIONS, MAX_CONSTRAINTS, MAX_GROUPS, MAX_SESSIONS = 64, 32, 16, 256
 MOER_ROWS, MOER_COLS, EPISODE_STEPS = 289, 37, 288
 
@@ -94,6 +94,8 @@ SIGNATURES = {
     'evc_set_env_scalars': (_i32, [_vp, _vp]),
     'evc_get_station_state': (_i32, [_vp, _vp, _vp, _vp]),
     'evc_set_station_state': (_i32, [_vp, _vp, _vp, _vp]),
+    'evc_get_entry_rank': (_i32, [_vp, _vp]),
+    'evc_set_station_state_ranked': (_i32, [_vp, _vp, _vp, _vp, _vp]),
     'evc_get_breakdown': (_i32, [_vp, _vp]),
     'evc_set_breakdown': (_i32, [_vp, _vp]),
     'evc_clear_status': (_i32, [_vp]),

@@ -9,6 +9,13 @@
 // traffic shrinks from 2 x 12 n bytes to 12 x 16 bytes read plus 12 A written.  What stays station-shaped is the interface: the action row is read densely (range
 // check) and exchanged to the entries through LDS; demands / est_departures of the observation are
 // scattered by the entries into a per-row LDS image and written out densely.
+//   * round 6 — the station side moves in 16-BYTE accesses: lane q owns stations 4q .. 4q+3 of the action row (one
+//     buffer_load_dwordx4 + one ds_write_b128 instead of four of each); the observation image is kept in the ORDER OF THE
+//     OBSERVATION ROW ([demands n | est_departures n], contiguous), so lane q reads whole 16-byte chunks q and q + 16 of it
+//     (ds_read_b128) and stores them as they are (buffer_store_dwordx4), and the row's tail [forecasted_moer k | prev_moer |
+//     timestep] comes as ONE 16-byte load per lane from a table the engine keeps in that order (Params::off_mtail) and leaves as
+//     one store: 4 stores per lane and row instead of 11, 2 loads instead of 7 (Caltech, n = 54, k = 36).  The delivered amps
+//     are summed over the entries (as the fused rollout kernel does), not through the image.
 //   * unplug = an entry with departure <= t+1 is simply not written back; survivors are packed by a
 //     ballot prefix count; a plug-in event appends one entry (written straight to memory and to the
 //     observation image by lane 0 of the row).  Entries never move between lanes.
@@ -24,10 +31,7 @@
 
 namespace evc {
 
-struct alignas(16) StationCell {
-    float demand, est_rel;
-    double amps;
-};
+constexpr int kImgFloats = 128;          // observation image of one environment: [demands n | est_departures n], 2 n <= 128 floats
 
 #ifndef EVC_CQUAD_WAVES
 #define EVC_CQUAD_WAVES 4
@@ -41,12 +45,11 @@ struct CquadLds {
     LdsNet net;
     union Images {
         struct {
-            // [wave][row][station] image the entries scatter into and the station lanes read back: observation
-            // fields + delivered amps (summed in station order: the result does not depend on the entry order,
-            // i.e. not on the history of plug-ins, and equals the station-layout kernels' bit for bit); zero
+            // [wave][row] image the entries scatter into and the station lanes read back in 16-byte chunks: the first 2 n
+            // floats of the observation row, in its order (demand of station s at [s], est_departure at [n + s]); zero
             // between steps
-            StationCell obs_img[4][4][64];
-            float act_img[4][4][64];    // [wave][row][station] clamped action of this step
+            alignas(16) float obs_img[4][4][kImgFloats];
+            alignas(16) float act_img[4][4][64];    // [wave][row][station] clamped action of this step
         } s;
         SolverWs solver_workspace;
     } u;
@@ -113,17 +116,22 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     const unsigned m = (unsigned)P.m, k = (unsigned)P.k;
     const unsigned N = (unsigned)P.N;
 
-    // dense side: station j*16+q of the row (action range check, observation stores)
+    // dense side: lane q owns stations 4q + j, j = 0..3 (action range check, act image, per-station debug outputs)
+    const unsigned st4 = q * 4u;
     bool st_valid[kSlots];
 #pragma unroll
-    for (int j = 0; j < kSlots; j++) st_valid[j] = (unsigned)j * 16u + q < n;
+    for (int j = 0; j < kSlots; j++) st_valid[j] = st4 + (unsigned)j < n;
+    // observation row as 16-byte chunks: [demands | est_departures] = 2 n floats = c_full whole chunks (+ a 2-float one if n is
+    // odd); tail [forecasted_moer k | prev_moer | timestep] = k + 2 floats = t_full whole chunks + t_rem floats
+    const unsigned c_full = (2u * n) >> 2, t_full = (k + 2u) >> 2, t_rem = (k + 2u) & 3u;
+    const unsigned t_chunks = (unsigned)P.mtail_w >> 2;
 
     const rsrc_t r_win = row_rsrc(P.win_base, P.win_span);      // every engine-owned array (struct Win)
     const Win r_rem{r_win, P.off_rem}, r_de{r_win, P.off_de};
     const rsrc_t r_act = row_rsrc(io.actions, (!DBG || io.actions) ? N * n * 4u : 0u);
     const Win r_scal{r_win, P.off_scal}, r_acc{r_win, P.off_acc};
     const rsrc_t r_obs = row_rsrc(io.out.obs, N * F * 4u);
-    const Win r_moer{r_win, P.off_moer}, r_hist{r_win, P.off_hist};
+    const Win r_mtail{r_win, P.off_mtail}, r_hist{r_win, P.off_hist};
     const rsrc_t r_rew = row_rsrc(io.out.reward, N * 8u);
     const rsrc_t r_term = row_rsrc(io.out.terminated, N);
     const rsrc_t r_bd = row_rsrc(io.out.breakdown, io.out.breakdown ? N * 24u : 0u);
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         v4u s0, s1;
         unsigned meta0;
         double rem0;
-        float a[kSlots];
+        v4u a4;                     // actions of stations 4q .. 4q+3
     };
     auto issue = [&](int quad_) {
         QuadRaw L;
@@ -169,9 +177,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // dependent load would cost a second round trip
         L.meta0 = buf_ld_u32(r_de, ev_ ? (eb_ + q) * 4u : kOob);
         L.rem0 = buf_ld_f64(r_rem, ev_ ? (eb_ + q) * 8u : kOob);
-#pragma unroll
-        for (int j = 0; j < kSlots; j++)
-            L.a[j] = greedy ? 0.0f : buf_ld_f32(r_act, (ev_ && st_valid[j]) ? (eb_ + (unsigned)j * 16u + q) * 4u : kOob);
+        // one 16-byte load (rows are n * 4 bytes apart: 4- or 8-byte aligned, which buffer accesses allow; the range check is
+        // per dword, tools/probes/b128_probe.hip); a lane whose chunk runs past station n - 1 reads the head of the next row
+        // there (zeros behind the last row) and masks it with st_valid
+        L.a4 = v4u{0u, 0u, 0u, 0u};
+        if (!greedy) L.a4 = buf_ld_v4(r_act, (ev_ && st_valid[0]) ? (eb_ + st4) * 4u : kOob);
         return L;
     };
     // The first quad's loads are issued before the LDS tables are built: the two latency chains (network
@@ -199,15 +209,18 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         st_mulw_hi[s] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
         st_info[s] = (unsigned char)((unsigned)gid | ((unsigned)((P.cc_mask >> s) & 1ull) << 7));
     }
-#pragma unroll
-    for (int j = 0; j < kSlots; j++) {
-        obs_img[wv][row][j * 16 + q] = StationCell{0.0f, 0.0f, 0.0};
-        act_img[wv][row][j * 16 + q] = 0.0f;
-        if (DBG) dbg_img[wv][row][j * 16 + q] = 0.0;
+    {
+        float4* const img4 = reinterpret_cast<float4*>(obs_img[wv][row]);
+        img4[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        img4[16u + q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        reinterpret_cast<float4*>(act_img[wv][row])[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+#pragma unroll
+    for (int j = 0; j < kSlots; j++)
+        if (DBG) dbg_img[wv][row][st4 + j] = 0.0;
     stage_net(net, P);                              // ends with the workgroup barrier
 
-    StationCell* const obs_row = obs_img[wv][row];
+    float* const obs_row = obs_img[wv][row];        // [demands n | est_departures n]
     float* const act_row = act_img[wv][row];
     double* const dbg_row = dbg_img[DBG ? wv : 0][row];
 
@@ -252,13 +265,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 #pragma unroll
         for (int j = 0; j < kSlots; j++) a_st[j] = 0.0f;
         if (!greedy) {
+            const float a_in[kSlots] = {__uint_as_float(cur.a4.x), __uint_as_float(cur.a4.y), __uint_as_float(cur.a4.z), __uint_as_float(cur.a4.w)};
 #pragma unroll
             for (int j = 0; j < kSlots; j++) {
-                const float a = cur.a[j];
+                const float a = a_in[j];
                 a_st[j] = fminf(fmaxf(a, 0.0f), 1.0f);                    // NaN -> 0
-                clamped = clamped || (a_st[j] != a);                      // also true for NaN
-                act_row[j * 16 + q] = a_st[j];
+                clamped = clamped || (st_valid[j] && a_st[j] != a);       // also true for NaN
             }
+            reinterpret_cast<float4*>(act_row)[q] = make_float4(a_st[0], a_st[1], a_st[2], a_st[3]);
         }
         // Without the projection the schedule of EMPTY stations is non-zero too and counts in the
         // constraint excess (env.py:449-452 evaluates the schedule, not the delivered rates): the
@@ -286,21 +300,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // (i)+(ii) 22.52 -> 22.29 / 26.32 -> 26.06.
         constexpr bool kEarly = PROJECT;
         double moer_now0 = 0.0;
-        float mo0[3] = {0.0f, 0.0f, 0.0f};
+        v4u mo0 = {0u, 0u, 0u, 0u};
         v2u sv0 = {0u, 0u};
         double rq0 = 0.0;
         unsigned nx0 = 0u;
         if constexpr (kEarly) {
             const unsigned mrow0 = live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) : 0u;
             moer_now0 = buf_ld_f64(r_hist, live ? mrow0 * 8u : kOob);
-#pragma unroll
-            for (int p = 0; p < 3; p++) {
-                const unsigned idx = (unsigned)p * 16u + q;             // position in [forecast | prev | ts]
-                const unsigned col = idx < k ? idx + 1u : 0u;
-                const unsigned o_moer = P.off_moer + (mrow0 * EVC_MOER_COLS + col) * 4u;
-                const unsigned o_ts = P.off_ts + (unsigned)t1 * 4u;
-                mo0[p] = buf_ld_f32(r_win, (live && idx <= k + 1u) ? (idx <= k ? o_moer : o_ts) : kOob);
-            }
+            mo0 = buf_ld_v4(r_mtail, (live && q < t_chunks) ? (mrow0 * (unsigned)P.mtail_w + st4) * 4u : kOob);   // chunk q of [forecast | prev | ts]
             const bool pend0 = live && next_arrival <= t1 && cursor < n_sessions;
             const unsigned sidx0 = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
             sv0 = buf_ld_v2(r_sess, pend0 ? sidx0 * 8u : kOob);
@@ -470,16 +477,16 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                     if (cross[c]) amps[c] = charge_ev_cross(pilot[c], rem_in[c], rem[c]);
             }
         }
+        double amps_sum = 0.0;                     // env.py:445: delivered amps, summed over the entries (order: slot, then lane)
 #pragma unroll
-        for (int c = 0; c < NS; c++)
-            if (live && valid[c]) obs_row[st[c]].amps = amps[c];
+        for (int c = 0; c < NS; c++) amps_sum += (live && valid[c]) ? amps[c] : 0.0;
         double pilot_st[kSlots];                   // station-side pilots (station_pilots only)
 #pragma unroll
         for (int j = 0; j < kSlots; j++) pilot_st[j] = 0.0;
         if (station_pilots) {
 #pragma unroll
             for (int j = 0; j < kSlots; j++) {
-                const unsigned s = (unsigned)j * 16u + q;
+                const unsigned s = (st4 + (unsigned)j) & 63u;
                 const unsigned info = st_info[s];
                 pilot_st[j] = st_valid[j] ? legal_pilot((double)a_st[j] * Consts::ACTION_SCALE_FACTOR, (info >> 7) != 0u) : 0.0;
                 unsigned mw[WORDS];
@@ -533,20 +540,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // MOER loads for t1 (row-uniform addresses); issued here rather than at the top of the iteration: the values are
         // only stored at its end, and four VGPRs fewer alive through the charge section are worth 0.8 us per step
         double moer_now = moer_now0;
-        float mo[3] = {mo0[0], mo0[1], mo0[2]};
+        v4u mo = mo0;
         if constexpr (!kEarly) {
         const unsigned mrow = live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) : 0u;
         moer_now = buf_ld_f64(r_hist, live ? mrow * 8u : kOob);
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            const unsigned idx = (unsigned)p * 16u + q;                 // position in [forecast | prev | ts]
-            const unsigned col = idx < k ? idx + 1u : 0u;
-            // one load per lane: MOER columns and the timestep table live in the same window
-            const unsigned o_moer = P.off_moer + (mrow * EVC_MOER_COLS + col) * 4u;
-            const unsigned o_ts = P.off_ts + (unsigned)t1 * 4u;
-            const unsigned o = idx <= k ? o_moer : o_ts;
-            mo[p] = buf_ld_f32(r_win, (live && idx <= k + 1u) ? o : kOob);
-        }
+        mo = buf_ld_v4(r_mtail, (live && q < t_chunks) ? (mrow * (unsigned)P.mtail_w + st4) * 4u : kOob);       // chunk q of [forecast | prev | ts]
         }
 
         if (live) t = t1;
@@ -573,8 +571,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                     buf_st_u32(r_de, (ebase + count) * 4u, pack_entry(s_dep, (int)s_st, s_est));
                     buf_st_f64(r_rem, (ebase + count) * 8u, rq);
                     const bool active = rq > Consts::FULLY_CHARGED_EPS;
-                    obs_row[s_st].demand = active ? (float)rq : 0.0f;
-                    obs_row[s_st].est_rel = active ? (float)(s_est - t) : 0.0f;
+                    obs_row[s_st] = active ? (float)rq : 0.0f;
+                    obs_row[n + s_st] = active ? (float)(s_est - t) : 0.0f;
                 }
                 count += 1u;
                 arrived |= 1ull << s_st;
@@ -602,7 +600,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 #pragma unroll
                     for (int j = 0; j < kSlots; j++)
                         if (live && st_valid[j])
-                            outs[o][(size_t)ebase + (unsigned)j * 16u + q] = o == 0 ? pilot_st[j] : (double)a_st[j];
+                            outs[o][(size_t)ebase + st4 + (unsigned)j] = o == 0 ? pilot_st[j] : (double)a_st[j];
                     continue;
                 }
 #pragma unroll
@@ -612,8 +610,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                 lds_sync();
 #pragma unroll
                 for (int j = 0; j < kSlots; j++) {
-                    const double v = dbg_row[j * 16 + q];
-                    if (live && st_valid[j]) outs[o][(size_t)ebase + (unsigned)j * 16u + q] = v;
+                    const double v = dbg_row[(st4 + (unsigned)j) & 63u];
+                    if (live && st_valid[j]) outs[o][(size_t)ebase + st4 + (unsigned)j] = v;
                 }
                 lds_sync();
 #pragma unroll
@@ -634,21 +632,19 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         auto scatter_obs = [&](int c) {
             if (live && alive[c]) {
                 const bool active = rem[c] > Consts::FULLY_CHARGED_EPS;
-                obs_row[st[c]].demand = active ? (float)rem[c] : 0.0f;
-                obs_row[st[c]].est_rel = active ? (float)(est[c] - t) : 0.0f;
+                obs_row[st[c]] = active ? (float)rem[c] : 0.0f;
+                obs_row[n + st[c]] = active ? (float)(est[c] - t) : 0.0f;
             }
         };
 #pragma unroll
         for (int c = 0; c < NS; c++) scatter_obs(c);
         lds_sync();
-        float2 d[kSlots];
-        double amps_sum = 0.0;
+        float4 d[2];                                // chunks q and q + 16 of [demands | est_departures]
 #pragma unroll
-        for (int j = 0; j < kSlots; j++) {
-            const StationCell cell = obs_row[j * 16 + q];
-            obs_row[j * 16 + q] = StationCell{0.0f, 0.0f, 0.0};  // leave the image clean for the next step
-            d[j] = make_float2(cell.demand, cell.est_rel);
-            amps_sum += cell.amps;
+        for (int p = 0; p < 2; p++) {
+            float4* const chunk = reinterpret_cast<float4*>(obs_row) + ((unsigned)p * 16u + q);
+            d[p] = *chunk;
+            *chunk = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // leave the image clean for the next step
         }
         const double total_rate = row_allreduce_f64(amps_sum);           // env.py:445
 
@@ -664,23 +660,31 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         buf_st_u8(r_term, (wr && q == 0u) ? env : kOob, (done || after_done) ? 1 : 0);
         buf_st_f64(r_bd, (live && q < 3u) ? env * 24u + q * 8u : kOob, acc);
 
+        // The observation row leaves as 16-byte chunks: [demands | est_departures] from the image (d[0], d[1]), the tail
+        // [forecasted_moer | prev_moer | timestep] from the table row (mo).  Whole chunks are dwordx4 stores; what the row
+        // lengths leave over (2 floats of the first part when n is odd, (k + 2) mod 4 of the tail) goes behind wave-uniform
+        // branches: for n = 54, k = 36 that is 2 + 1 stores of 16 bytes and one of 8.
+        auto store_obs = [&](const rsrc_t& r, bool w) {
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const unsigned c = (unsigned)p * 16u + q;
+                const v4u v = {__float_as_uint(d[p].x), __float_as_uint(d[p].y), __float_as_uint(d[p].z), __float_as_uint(d[p].w)};
+                buf_st_v4(r, (w && c < c_full) ? (obase + c * 4u) * 4u : kOob, v);
+                if (n & 1u) buf_st_v2(r, (w && c == c_full) ? (obase + c * 4u) * 4u : kOob, v2u{v.x, v.y});
+            }
+            const unsigned tb = (obase + 2u * n + st4) * 4u;
+            buf_st_v4(r, (w && q < t_full) ? tb : kOob, mo);
+            if (t_rem & 2u) buf_st_v2(r, (w && q == t_full) ? tb : kOob, v2u{mo.x, mo.y});
+            if (t_rem & 1u) buf_st_u32(r, (w && q == t_full) ? tb + (t_rem & 2u) * 4u : kOob, (t_rem & 2u) ? mo.z : mo.x);
+        };
+
         // ---- autoreset (gymnasium VectorEnv): terminal observation, then next episode's state ----
         const bool do_reset = done && P.autoreset;
         if (done) episodes += 1;
         if (__builtin_expect(__ballot(do_reset) != 0ull, 0)) {
             if (io.out.final_obs) {
                 const rsrc_t r_fin = row_rsrc(io.out.final_obs, N * F * 4u);
-#pragma unroll
-                for (int j = 0; j < kSlots; j++) {
-                    const unsigned o = (do_reset && st_valid[j]) ? (obase + (unsigned)j * 16u + q) * 4u : kOob;
-                    buf_st_f32(r_fin, o, d[j].x);
-                    buf_st_f32(r_fin, o == kOob ? kOob : o + n * 4u, d[j].y);
-                }
-#pragma unroll
-                for (int p = 0; p < 3; p++) {
-                    const unsigned idx = (unsigned)p * 16u + q;
-                    buf_st_f32(r_fin, (do_reset && idx < k + 2u) ? (obase + 2u * n + idx) * 4u : kOob, mo[p]);
-                }
+                store_obs(r_fin, do_reset);
             }
             if (do_reset) {
                 const int next = (slot + P.autoreset_stride) % P.bank_slots;
@@ -693,32 +697,16 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                 n_sessions = P.n_sessions[next];
                 next_arrival = n_sessions > 0 ? first_arrival : kNoArrival;
                 count = 0u;
-#pragma unroll
-                for (int j = 0; j < kSlots; j++) d[j] = make_float2(0.0f, 0.0f);
+                d[0] = d[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
+            // first observation of the next episode: the table's row of period 0 (timestep 0)
             const unsigned mrow0 = (unsigned)moer_day * EVC_MOER_ROWS;
-#pragma unroll
-            for (int p = 0; p < 3; p++) {
-                const unsigned idx = (unsigned)p * 16u + q;
-                const unsigned col = idx < k ? idx + 1u : 0u;
-                const float v = buf_ld_f32(r_moer, (do_reset && idx <= k) ? (mrow0 * EVC_MOER_COLS + col) * 4u : kOob);
-                if (do_reset) mo[p] = (idx == k + 1u) ? 0.0f : v;
-            }
+            const v4u v = buf_ld_v4(r_mtail, (do_reset && q < t_chunks) ? (mrow0 * (unsigned)P.mtail_w + st4) * 4u : kOob);
+            if (do_reset) mo = v;
         }
 
         // ---- observation (env.py:381-394) + state write-back ----
-#pragma unroll
-        for (int j = 0; j < kSlots; j++) {
-            const bool w = live && st_valid[j];
-            const unsigned o = (obase + (unsigned)j * 16u + q) * 4u;
-            buf_st_f32(r_obs, w ? o : kOob, d[j].x);
-            buf_st_f32(r_obs, w ? o + n * 4u : kOob, d[j].y);
-        }
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            const unsigned idx = (unsigned)p * 16u + q;
-            buf_st_f32(r_obs, (live && idx < k + 2u) ? (obase + 2u * n + idx) * 4u : kOob, mo[p]);
-        }
+        store_obs(r_obs, live);
         auto store_entry = [&](int c) {
             const bool w = live && alive[c] && !do_reset;
             buf_st_u32(r_de, w ? (ebase + pos[c]) * 4u : kOob, meta[c]);

@@ -128,6 +128,8 @@ struct Params {
     const char* win_base;
     unsigned win_span;
     unsigned off_rem, off_de, off_scal, off_acc, off_sess, off_req, off_hist, off_moer, off_ts;
+    unsigned off_mtail;            // float[moer_days][289][mtail_w]: observation tail [forecast 1..k | prev | timestep | 0 pad], 16-byte rows
+    int mtail_w;                   // floats per row of that table: k + 2 rounded up to a multiple of 4
     // slow-path queue (environments whose projection needs the iterative solver)
     int* slow_count;               // control block {count, ticket} this step appends to
     int* slow_count_next;          // control block the drainer clears for the next step
@@ -183,6 +185,15 @@ __device__ __forceinline__ void buf_st_f32(rsrc_t r, unsigned off, float x) {
 }
 __device__ __forceinline__ void buf_st_u8(rsrc_t r, unsigned off, unsigned char x) {
     __builtin_amdgcn_raw_buffer_store_b8(x, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ v4u buf_ld_v4(rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void buf_st_v4(rsrc_t r, unsigned off, v4u x) {
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void buf_st_v2(rsrc_t r, unsigned off, v2u x) {
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, (int)off, 0, 0);
 }
 __device__ __forceinline__ void buf_st_i4(rsrc_t r, unsigned off, int4 x) {
     v4u v;

@@ -80,6 +80,7 @@ struct evc_engine {
     int* d_slot_moer = nullptr;
     double* d_moer_hist = nullptr;
     float* d_moer_obs = nullptr;
+    float* d_moer_tail = nullptr;        // [moer_days][289][mtail_w]: the observation row's tail, ready to store (Params::off_mtail)
     NetTables* d_tables = nullptr;
     int* d_slow_count = nullptr;  // [2 halves][2]: queue length per step parity (second pair: the second half launch of the pipelined mode); [4..5]: always zero, for the warm-up launches
     int* d_slow_list = nullptr;
@@ -844,6 +845,10 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
         const size_t o_hist = piece(sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS);
         const size_t o_moer = piece(sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS);
         const size_t o_tab = piece(sizeof(NetTables));
+        // observation-ordered MOER rows for the compact streaming kernel's 16-byte accesses: [forecast 1..k | prev | timestep | 0 ...],
+        // k + 2 floats padded to whole 16-byte chunks
+        P.mtail_w = (P.k + 2 + 3) & ~3;
+        const size_t o_mtail = piece(sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * (size_t)P.mtail_w);
         A(hipMalloc((void**)&e->d_arena, total));
         if (err == hipSuccess) {
             char* b = e->d_arena;
@@ -851,6 +856,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
             e->d_acc = (double*)(b + o_acc); e->d_sessions = (evc_session*)(b + o_sess);
             e->d_requested = (double*)(b + o_req); e->d_moer_hist = (double*)(b + o_hist);
             e->d_moer_obs = (float*)(b + o_moer); e->d_tables = (NetTables*)(b + o_tab);
+            e->d_moer_tail = (float*)(b + o_mtail);
         }
     }
     A(dmalloc(&e->d_nsess, (size_t)bank_slots));
@@ -877,6 +883,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(hipMemset(e->d_maxprofit, 0, sizeof(double) * (size_t)bank_slots));
     A(hipMemset(e->d_moer_hist, 0, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS));
     A(hipMemset(e->d_moer_obs, 0, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS));
+    A(hipMemset(e->d_moer_tail, 0, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * (size_t)P.mtail_w));
     A(hipMemset(e->d_slow_count, 0, 6 * sizeof(int)));
     A(hipMemset(e->d_tie, 0, 2 * kTieSlots * sizeof(unsigned long long)));
     A(hipMemset(e->d_slow_list, 0xff, sizeof(int) * N));
@@ -911,7 +918,8 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
             {Q.requested, sizeof(double) * (size_t)bank_slots * max_sessions, &Q.off_req},
             {Q.moer_hist, sizeof(double) * (size_t)moer_days * EVC_MOER_ROWS, &Q.off_hist},
             {Q.moer_obs, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * EVC_MOER_COLS, &Q.off_moer},
-            {e->d_tables->timestep, sizeof(float) * EVC_MOER_ROWS, &Q.off_ts}};
+            {e->d_tables->timestep, sizeof(float) * EVC_MOER_ROWS, &Q.off_ts},
+            {e->d_moer_tail, sizeof(float) * (size_t)moer_days * EVC_MOER_ROWS * (size_t)Q.mtail_w, &Q.off_mtail}};
         uintptr_t lo = UINTPTR_MAX, hi = 0;
         for (const Arr& a : arrs) {
             lo = std::min(lo, (uintptr_t)a.p);
@@ -1029,6 +1037,17 @@ int evc_upload_moer(evc_engine* e, int32_t first_day, int32_t num_days, const do
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(copy_h2d(e->d_moer_hist + (size_t)first_day * EVC_MOER_ROWS, hist.data(), sizeof(double) * rows, e->stream));
     HIP_TRY(copy_h2d(e->d_moer_obs + (size_t)first_day * EVC_MOER_ROWS * EVC_MOER_COLS, obs.data(), sizeof(float) * rows * EVC_MOER_COLS, e->stream));
+    {   // the same values in observation order (env.py:390-392: forecast columns 1..k, prev = column 0, timestep), one padded row per period
+        const int k = e->P.k, w = e->P.mtail_w;
+        std::vector<float> tail(rows * (size_t)w, 0.0f);
+        for (size_t r = 0; r < rows; r++) {
+            float* row = &tail[r * (size_t)w];
+            for (int c = 0; c < k; c++) row[c] = obs[r * EVC_MOER_COLS + 1 + c];
+            row[k] = obs[r * EVC_MOER_COLS];
+            row[k + 1] = (float)((double)(r % EVC_MOER_ROWS) / (double)EVC_EPISODE_STEPS);
+        }
+        HIP_TRY(copy_h2d(e->d_moer_tail + (size_t)first_day * EVC_MOER_ROWS * (size_t)w, tail.data(), sizeof(float) * rows * (size_t)w, e->stream));
+    }
     return EVC_OK;
 }
 
@@ -1441,7 +1460,32 @@ int evc_get_station_state(evc_engine* e, double* rem, int16_t* dep, int16_t* est
     return EVC_OK;
 }
 
+int evc_get_entry_rank(evc_engine* e, int16_t* rank) {
+    if (!e || !rank) return fail(EVC_EINVAL, "null argument");
+    if (int rc = bind(e)) return rc;
+    const size_t N = (size_t)e->P.N, n = (size_t)e->P.n, cnt = N * n;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<int> de(cnt);
+    HIP_TRY(copy_d2h(de.data(), e->d_depest, sizeof(int) * cnt, e->stream));
+    if (!e->compact) {
+        for (size_t i = 0; i < cnt; i++) rank[i] = (int16_t)(de[i] & 0xffff) == (int16_t)kEmptyDep ? (int16_t)-1 : (int16_t)(i % n);
+        return EVC_OK;
+    }
+    std::vector<int> sc(N * 8);
+    HIP_TRY(copy_d2h(sc.data(), e->d_scal, sizeof(int4) * 2 * N, e->stream));
+    for (size_t i = 0; i < cnt; i++) rank[i] = -1;
+    for (size_t env = 0; env < N; env++) {
+        const int A = (sc[env * 8 + 6] >> kCountShift) & 0x7f;
+        for (int a = 0; a < A; a++) rank[env * n + (size_t)entry_station((unsigned)de[env * n + a])] = (int16_t)a;
+    }
+    return EVC_OK;
+}
+
 int evc_set_station_state(evc_engine* e, const double* rem, const int16_t* dep, const int16_t* est) {
+    return evc_set_station_state_ranked(e, rem, dep, est, nullptr);
+}
+
+int evc_set_station_state_ranked(evc_engine* e, const double* rem, const int16_t* dep, const int16_t* est, const int16_t* rank) {
     if (!e || !rem || !dep || !est) return fail(EVC_EINVAL, "null argument");
     if (int rc = bind(e)) return rc;
     const size_t N = (size_t)e->P.N, n = (size_t)e->P.n, cnt = N * n;
@@ -1456,13 +1500,23 @@ int evc_set_station_state(evc_engine* e, const double* rem, const int16_t* dep, 
     std::vector<double> rc(cnt, 0.0);
     std::vector<int> sc(N * 8);
     HIP_TRY(copy_d2h(sc.data(), e->d_scal, sizeof(int4) * 2 * N, e->stream));
+    std::vector<size_t> order;
     for (size_t env = 0; env < N; env++) {
-        int A = 0;
+        order.clear();
         for (size_t s = 0; s < n; s++) {
             const size_t i = env * n + s;
             if (dep[i] == kEmptyDep) continue;
             if (dep[i] < 0 || dep[i] > EVC_EPISODE_STEPS)
                 return fail(EVC_EINVAL, "evc_set_station_state: departure %d outside [0,288]", (int)dep[i]);
+            if (rank && (rank[i] < 0 || (size_t)rank[i] >= n))
+                return fail(EVC_EINVAL, "evc_set_station_state_ranked: entry_rank %d of an occupied EVSE outside [0,%d)", (int)rank[i], (int)n);
+            order.push_back(s);
+        }
+        // the environment's list: by entry_rank where given (ties by station), else in station order
+        if (rank) std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return rank[env * n + a] < rank[env * n + b]; });
+        int A = 0;
+        for (const size_t s : order) {
+            const size_t i = env * n + s;
             rc[env * n + A] = rem[i];
             de[env * n + A] = (int)pack_entry(dep[i], (int)s, est[i]);
             A++;

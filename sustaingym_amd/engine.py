@@ -438,8 +438,12 @@ class StepEngine:
         rem, dep, est = self.station_state()
         acc = np.zeros((self.N, 3), np.float64)
         check(self.lib.evc_get_breakdown(self.handle, _np_ptr(acc)), 'evc_get_breakdown')
+        # order of the plugged-in EVs in each environment's entry list (compact layout): the delivered amps are summed in
+        # that order, so it is part of a checkpoint that replays bit for bit (evcharge.h, ABI 7)
+        rank = np.zeros((self.N, self.n), np.int16)
+        check(self.lib.evc_get_entry_rank(self.handle, _np_ptr(rank)), 'evc_get_entry_rank')
         return {'scalars': raw, 'remaining_kwh': rem, 'departure': dep, 'est_departure': est,
-                'breakdown': acc}
+                'breakdown': acc, 'entry_rank': rank}
 
     def set_state(self, state: dict[str, np.ndarray]) -> None:
         raw = np.ascontiguousarray(state['scalars'], dtype=np.int32)
@@ -448,8 +452,11 @@ class StepEngine:
         est = np.ascontiguousarray(state['est_departure'], dtype=np.int16)
         acc = np.ascontiguousarray(state['breakdown'], dtype=np.float64)
         check(self.lib.evc_set_env_scalars(self.handle, _np_ptr(raw)), 'evc_set_env_scalars')
-        check(self.lib.evc_set_station_state(self.handle, _np_ptr(rem), _np_ptr(dep), _np_ptr(est)),
-              'evc_set_station_state')
+        rank = state.get('entry_rank')                # absent (older checkpoints, hand-made states): station order
+        if rank is not None:
+            rank = np.ascontiguousarray(rank, dtype=np.int16)
+        check(self.lib.evc_set_station_state_ranked(self.handle, _np_ptr(rem), _np_ptr(dep), _np_ptr(est), _np_ptr(rank)),
+              'evc_set_station_state_ranked')
         check(self.lib.evc_set_breakdown(self.handle, _np_ptr(acc)), 'evc_set_breakdown')
 
     def clear_status(self) -> None:
