@@ -187,6 +187,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     // The first quad's loads are issued before the LDS tables are built: the two latency chains (network
     // tables from global memory, first state / action rows) overlap instead of following each other —
     // a wave runs only four iterations at N = 65 536, so the prologue is a visible share of the launch.
+#ifdef EVC_TIMELINE     /* measurement builds (tools/wg_timeline.py): 16 time stamps (100 MHz) per wavefront into Params::slow_list */
+    unsigned* const tl_buf = (unsigned*)P.slow_list + ((blockIdx.x * 4u + wv) & 4095u) * 16u;
+    int tl_it = 0;
+    auto tl_stamp = [&](int k) { if (lane == 0u && k < 16) tl_buf[k] = (unsigned)__builtin_amdgcn_s_memrealtime(); };
+    tl_stamp(0);
+#endif
     QuadRaw nxt = issue(walk.first < walk.hi ? walk.first : -1);
 
     if (tid == 0u) S.next_quad = 4;
@@ -196,18 +202,16 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // the host (drain mode decision) and clear it for the next step
         if (blockIdx.x == 0u) queue_begin_drain(P, P.slow_count_next[0]);               // (a half launch of the pipelined mode has control blocks of its own)
     }
-    if (tid < 64u) {
-        const unsigned s = tid;
-        const bool valid = s < n;
-        int gid = 0;
-        for (int g = 0; g < P.G; g++)
-            if ((P.group_mask[g] >> s) & 1ull) gid = g;
-        unsigned mw[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) mw[w] = (valid && (gid >> 1) == w) ? ((gid & 1) ? 65536u : 1u) : 0u;
-        st_mulw[s] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-        st_mulw_hi[s] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
-        st_info[s] = (unsigned char)((unsigned)gid | ((unsigned)((P.cc_mask >> s) & 1ull) << 7));
+    // network tables, class multipliers and EVSE kinds: the chunk list the engine prepared (Params::cq_blob).  Addresses depend
+    // on the thread id alone, so the list entry and its data are requested together: one round trip.
+    {
+        const CqBlob* const B = P.cq_blob;
+        const unsigned count = B->count;
+        for (unsigned i = tid; i < count; i += 256u) {
+            const unsigned d = B->dst[i];
+            const uint4 v = B->data[i];
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(&S) + d) = v;
+        }
     }
     {
         float4* const img4 = reinterpret_cast<float4*>(obs_img[wv][row]);
@@ -218,8 +222,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 #pragma unroll
     for (int j = 0; j < kSlots; j++)
         if (DBG) dbg_img[wv][row][st4 + j] = 0.0;
-    stage_net(net, P);                              // ends with the workgroup barrier
+    __syncthreads();
 
+#ifdef EVC_TIMELINE
+    tl_stamp(1);
+#endif
     float* const obs_row = obs_img[wv][row];        // [demands n | est_departures n]
     float* const act_row = act_img[wv][row];
     double* const dbg_row = dbg_img[DBG ? wv : 0][row];
@@ -252,6 +259,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         const unsigned ebase = env * n;
         const unsigned obase = env * F;                     // observation row
         const QuadRaw cur = nxt;
+#ifdef EVC_TIMELINE
+        tl_stamp(2 + 2 * tl_it);
+#if EVC_TIMELINE >= 2       /* how long until everything outstanding (prefetched rows, the previous quad's stores) is in */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tl_stamp(3 + 2 * tl_it);
+#endif
+#endif
 
         const v4u s0 = cur.s0, s1 = cur.s1;
         unsigned meta[kSlots];
@@ -370,8 +384,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // ---- projection screen (PROJECT) ----
         bool pilots_screened = false;
         if (PROJECT) {
-#pragma unroll
-            for (int w = 0; w < WORDS; w++) ywords[w] = row_allreduce_u32(ywords[w]);
+            row_allreduce_words<WORDS>(ywords);
             bool maybe = false, maybe_p = false;
             if (q < m) {
                 const float mag2 = quad_mag2_f32<WORDS>(net, q, ywords);
@@ -510,8 +523,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                     for (int w = 0; w < WORDS; w++) pwords[w] = __umul24((unsigned)(int)pilot[c], mw[w]) + pwords[w];   // <= 32
                 }
             }
-#pragma unroll
-            for (int w = 0; w < WORDS; w++) pwords[w] = row_allreduce_u32(pwords[w]);
+            row_allreduce_words<WORDS>(pwords);
             bool maybe = false;
             if (q < m && !pilots_screened) maybe = !(quad_mag2_f32<WORDS>(net, q, pwords) < net.thr_p2[q]);
             if (__builtin_expect(__ballot(maybe && live) != 0ull, 0)) {   // rare: exact evaluation
@@ -624,6 +636,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // prefetch of the next quad's rows: issued here, after the charge / event section (its 15 VGPRs are not alive through
         // the register-hungry part of the iteration: 184 -> 155 spilled VGPRs, -0.7 us per step with synchronised phases);
         // nothing to fetch after the last quad
+#if defined(EVC_TIMELINE) && EVC_TIMELINE < 2
+        tl_stamp(3 + 2 * tl_it);
+#endif
 #ifndef EVC_PREFETCH_EARLY
         quad_next = take_quad();
         if (quad_next >= 0) nxt = issue(quad_next);
@@ -739,7 +754,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         }
         lds_sync();
         quad = quad_next;
+#ifdef EVC_TIMELINE
+        tl_it++;
+#endif
     }
+#ifdef EVC_TIMELINE
+    tl_stamp(14);
+#endif
 
     if (DRAIN) {
         __syncthreads();                       // every wave's queue entries are in the list; the images are free
@@ -750,6 +771,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 #endif
         }
     }
+#ifdef EVC_TIMELINE
+    tl_stamp(15);
+#endif
 }
 
 }  // namespace evc

@@ -81,6 +81,14 @@ struct NetTables {
     float timestep[EVC_MOER_ROWS];   // (float)((double)t / 288.0), env.py:392
 };
 
+constexpr int kCqBlobMaxChunks = 1024;     // Gp <= 16 rows x (2 x 16 + 2 x 8 chunks) + mag / thresholds + 132 station chunks < 1024
+struct CqBlob {
+    unsigned count;                          // chunks in use
+    unsigned pad[3];
+    unsigned dst[kCqBlobMaxChunks];          // byte offset of chunk i inside the workgroup's CquadLds
+    uint4 data[kCqBlobMaxChunks];
+};
+
 // Kernel parameters (passed by value; lives in kernarg memory -> scalar loads).
 struct Params {
     int N, n, m, G, k, F;
@@ -128,6 +136,11 @@ struct Params {
     const char* win_base;
     unsigned win_span;
     unsigned off_rem, off_de, off_scal, off_acc, off_sess, off_req, off_hist, off_moer, off_ts;
+    // Prologue image of the compact streaming kernel (evc_cquad.h, round 6): everything a workgroup used to DERIVE at its
+    // start — the [G][m] corner of the network tables, the per-station class multipliers and EVSE kinds — as a list of
+    // 16-byte chunks with their LDS byte offsets, built once at evc_create: the prologue is one pass of independent
+    // loads and LDS writes instead of index arithmetic, 64-bit mask loops and dependent table loads.
+    const struct CqBlob* cq_blob;
     unsigned off_mtail;            // float[moer_days][289][mtail_w]: observation tail [forecast 1..k | prev | timestep | 0 pad], 16-byte rows
     int mtail_w;                   // floats per row of that table: k + 2 rounded up to a multiple of 4
     // slow-path queue (environments whose projection needs the iterative solver)

@@ -80,6 +80,7 @@ struct evc_engine {
     int* d_slot_moer = nullptr;
     double* d_moer_hist = nullptr;
     float* d_moer_obs = nullptr;
+    CqBlob* d_cq_blob = nullptr;         // prologue image of the compact streaming kernel (Params::cq_blob)
     float* d_moer_tail = nullptr;        // [moer_days][289][mtail_w]: the observation row's tail, ready to store (Params::off_mtail)
     NetTables* d_tables = nullptr;
     int* d_slow_count = nullptr;  // [2 halves][2]: queue length per step parity (second pair: the second half launch of the pipelined mode); [4..5]: always zero, for the warm-up launches
@@ -192,7 +193,7 @@ void free_all(evc_engine* e) {
                     e->d_nsess, e->d_slot_moer,
                     e->d_slow_count, e->d_slow_list, e->d_idbuf, e->d_metrics, e->d_act, e->d_act_f32, e->d_obs,
                     e->d_reward, e->d_term, e->d_breakdown, e->d_final, e->d_pilots, e->d_rates,
-                    e->d_proj, e->d_maxprofit, e->d_gen, e->d_tie};
+                    e->d_proj, e->d_maxprofit, e->d_gen, e->d_tie, e->d_cq_blob};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ev : e->ev)
@@ -337,6 +338,49 @@ int build_tables(const evc_network_desc* net, Params& P, NetTables& T) {
                 if (T.Mre[g][c] * T.Mre[h][c] + T.Mim[g][c] * T.Mim[h][c] < -1e-12) P.monotone_rows = 0;
     if (const char* s = getenv("EVC_CAPS_SHORTCUT")) P.monotone_rows = P.monotone_rows && atoi(s) != 0;   // measurements: 0 disables the shortcut
     return EVC_OK;
+}
+
+// Prologue image of step_kernel_cquad (Params::cq_blob): the [Gp][m] corner of the network tables and the per-station
+// class multipliers / EVSE kinds exactly as the kernel's prologue used to derive them, cut into 16-byte chunks with the
+// byte offset each one has inside the workgroup's CquadLds.
+void build_cq_blob(const Params& P, const NetTables& T, CqBlob& B) {
+    memset(&B, 0, sizeof(B));
+    unsigned cnt = 0;
+    auto put_range = [&](size_t dst, const void* src, size_t bytes) {          // whole chunks; rows are wide enough to be over-read
+        for (size_t o = 0; o < bytes; o += 16) {
+            memcpy(&B.data[cnt], (const char*)src + o, 16);
+            B.dst[cnt++] = (unsigned)(dst + o);
+        }
+    };
+    const size_t m = (size_t)P.m, net0 = offsetof(CquadLds, net);
+    const int Gp = (P.G + 1) & ~1;                  // classes are padded to an even count (two per packed word); the pad row is zero
+    for (int g = 0; g < Gp; g++) {
+        put_range(net0 + offsetof(LdsNet, Mre) + sizeof(T.Mre[0]) * g, T.Mre[g], m * 8);
+        put_range(net0 + offsetof(LdsNet, Mim) + sizeof(T.Mim[0]) * g, T.Mim[g], m * 8);
+        put_range(net0 + offsetof(LdsNet, Mre32) + sizeof(T.Mre32[0]) * g, T.Mre32[g], m * 4);
+        put_range(net0 + offsetof(LdsNet, Mim32) + sizeof(T.Mim32[0]) * g, T.Mim32[g], m * 4);
+    }
+    put_range(net0 + offsetof(LdsNet, mag), T.mag, m * 8);
+    put_range(net0 + offsetof(LdsNet, thr_y2), T.thr_y2, m * 4);
+    put_range(net0 + offsetof(LdsNet, thr_p2), T.thr_p2, m * 4);
+    put_range(net0 + offsetof(LdsNet, thr_yp2), T.thr_yp2, m * 4);
+    uint4 lo[64], hi[64];
+    unsigned char info[64];
+    for (unsigned s = 0; s < 64; s++) {
+        const bool valid = s < (unsigned)P.n;
+        int gid = 0;
+        for (int g = 0; g < P.G; g++)
+            if ((P.group_mask[g] >> s) & 1ull) gid = g;
+        unsigned mw[8];
+        for (int w = 0; w < 8; w++) mw[w] = (valid && (gid >> 1) == w) ? ((gid & 1) ? 65536u : 1u) : 0u;
+        lo[s] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+        hi[s] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
+        info[s] = (unsigned char)((unsigned)gid | ((unsigned)((P.cc_mask >> s) & 1ull) << 7));
+    }
+    put_range(offsetof(CquadLds, st_mulw), lo, sizeof(lo));
+    if (P.G > 8) put_range(offsetof(CquadLds, st_mulw_hi), hi, sizeof(hi));      // packed words 4..7 exist only beyond eight classes
+    put_range(offsetof(CquadLds, st_info), info, sizeof(info));
+    B.count = cnt;
 }
 
 void compute_grids(evc_engine* e) {
@@ -867,6 +911,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(dmalloc(&e->d_tie, 2 * kTieSlots));
     A(dmalloc(&e->d_idbuf, 2 * N));
     A(dmalloc(&e->d_metrics, 8));
+    A(hipMalloc((void**)&e->d_cq_blob, sizeof(CqBlob)));
     if (err != hipSuccess) {
         free_all(e);
         delete e;
@@ -888,6 +933,12 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(hipMemset(e->d_tie, 0, 2 * kTieSlots * sizeof(unsigned long long)));
     A(hipMemset(e->d_slow_list, 0xff, sizeof(int) * N));
     A(copy_h2d(e->d_tables, &T, sizeof(T), e->stream));
+    {
+        std::vector<CqBlob> blob(1);
+        build_cq_blob(P, T, blob[0]);
+        A(copy_h2d(e->d_cq_blob, blob.data(), sizeof(CqBlob), e->stream));
+        P.cq_blob = e->d_cq_blob;
+    }
     for (auto& ev : e->ev) A(hipEventCreate(&ev));
     for (auto& ev : e->roll.ev) A(hipEventCreate(&ev));
     if (err != hipSuccess) {
@@ -1589,7 +1640,7 @@ int evc_last_slow_count(evc_engine* e, int32_t* count) {
     return EVC_OK;
 }
 
-#ifdef EVC_WG_TIMING
+#if defined(EVC_WG_TIMING) || defined(EVC_TIMELINE)
 int evc_debug_read_tie(evc_engine* e, unsigned long long* out /* [512] */, int clear) {
     if (hipStreamSynchronize(e->stream) != hipSuccess) return -4;
     if (copy_d2h(out, e->d_tie, sizeof(unsigned long long) * 2 * kTieSlots, e->stream) != hipSuccess) return -4;

@@ -34,6 +34,42 @@ __device__ __forceinline__ unsigned row_allreduce_u32(unsigned v) {
     v += dpp_ror_u32<0x128>(v);   // row_ror:8
     return v;
 }
+// The packed class-sum words of the streaming kernels, all of them through the four rotation steps together (round 6).
+// Written as v_add_u32_dpp by hand: the compiler fuses only some steps of row_allreduce_u32 into the add (the first one
+// disappears into the v_mad_u32_u24 that forms the word, the last one is kept as v_mov 0 + v_mov_dpp + v_add: 36 vector
+// instructions for three words instead of 12).  Words go in groups of up to three, interleaved: a DPP source written by a
+// vector instruction needs two wait states, which the other words of the group provide (s_nop where they do not, and in
+// front of the first step, whose inputs the compiler's own instructions have just written).
+#define EVC_DPP_ADD_(i, ctrl) "v_add_u32_dpp %" #i ", %" #i ", %" #i " " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void row_allreduce_u32x3(unsigned& a, unsigned& b, unsigned& c) {
+    asm("s_nop 1\n\t" EVC_DPP_ADD_(0, "row_ror:1") EVC_DPP_ADD_(1, "row_ror:1") EVC_DPP_ADD_(2, "row_ror:1")
+        EVC_DPP_ADD_(0, "row_ror:2") EVC_DPP_ADD_(1, "row_ror:2") EVC_DPP_ADD_(2, "row_ror:2")
+        EVC_DPP_ADD_(0, "row_ror:4") EVC_DPP_ADD_(1, "row_ror:4") EVC_DPP_ADD_(2, "row_ror:4")
+        EVC_DPP_ADD_(0, "row_ror:8") EVC_DPP_ADD_(1, "row_ror:8") EVC_DPP_ADD_(2, "row_ror:8")
+        : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void row_allreduce_u32x2(unsigned& a, unsigned& b) {
+    asm("s_nop 1\n\t" EVC_DPP_ADD_(0, "row_ror:1") EVC_DPP_ADD_(1, "row_ror:1") "s_nop 0\n\t"
+        EVC_DPP_ADD_(0, "row_ror:2") EVC_DPP_ADD_(1, "row_ror:2") "s_nop 0\n\t"
+        EVC_DPP_ADD_(0, "row_ror:4") EVC_DPP_ADD_(1, "row_ror:4") "s_nop 0\n\t"
+        EVC_DPP_ADD_(0, "row_ror:8") EVC_DPP_ADD_(1, "row_ror:8")
+        : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void row_allreduce_u32x1(unsigned& a) {
+    asm("s_nop 1\n\t" EVC_DPP_ADD_(0, "row_ror:1") "s_nop 1\n\t" EVC_DPP_ADD_(0, "row_ror:2") "s_nop 1\n\t"
+        EVC_DPP_ADD_(0, "row_ror:4") "s_nop 1\n\t" EVC_DPP_ADD_(0, "row_ror:8")
+        : "+v"(a));
+}
+#undef EVC_DPP_ADD_
+template <int WORDS>
+__device__ __forceinline__ void row_allreduce_words(unsigned (&w)[WORDS]) {
+    static_assert(WORDS >= 1 && WORDS <= 8, "packed class-sum words");
+    constexpr int kFull = WORDS / 3 * 3;
+#pragma unroll
+    for (int i = 0; i < kFull; i += 3) row_allreduce_u32x3(w[i], w[i + 1], w[i + 2]);
+    if constexpr (WORDS - kFull == 2) row_allreduce_u32x2(w[kFull], w[kFull + 1]);
+    if constexpr (WORDS - kFull == 1) row_allreduce_u32x1(w[kFull]);
+}
 // Sum over the 16 lanes of a row, IDENTICAL (bit for bit) on all of them: a butterfly — neighbours inside pairs, pairs inside
 // quads (quad_perm), quads inside halves (row_half_mirror), halves (row_mirror) — adds, at every level, the two halves of
 // a symmetric pair, and a + b == b + a exactly.  Rounds 1-2 used four rotations (row_ror 1, 2, 4, 8): the same cost, but

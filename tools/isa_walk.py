@@ -65,6 +65,7 @@ def main():
     log = []
     steps = 0
     undecided = 0
+    trace = open(dec['trace'], 'w') if dec.get('trace') else None
     while pc < len(ins) and steps < 200000:
         i = ins[pc]
         steps += 1
@@ -73,6 +74,8 @@ def main():
             break
         k = kind(i['op'])
         hist[i['line']][k] += 1
+        if trace is not None:
+            trace.write(f"{i['addr']:x}\t{i['line']}\t{i['op']} {i['args']}\n")
         ops[i['op'].replace('_e32','').replace('_e64','')] += 1
         total[k] += 1
         op = i['op']
