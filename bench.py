@@ -100,7 +100,7 @@ def headline_line(full: dict, full_path: str | None) -> dict:
         if isinstance(sec.get(key), dict) and 'env_steps_per_s' in sec[key]:
             scal[key + '_env_steps_per_s'] = sec[key]['env_steps_per_s']
     va = sec.get('vector_env_api') or {}
-    for key in ('torch', 'torch_pipeline2', 'torch_policy_greedy'):
+    for key in ('torch', 'torch_pipeline2', 'torch_caller_greedy', 'torch_policy_greedy', 'torch_pipeline2_policy_greedy'):
         if isinstance(va.get(key), dict) and 'ms_per_step' in va[key]:
             scal['vector_env_' + key + '_us_per_step'] = round(va[key]['ms_per_step'] * 1e3, 2)
     if scal:
@@ -679,6 +679,41 @@ def secondary_vector_env_api(dev_index, battery) -> dict:
     venv.close()
     out['torch_pipeline2'] = {'workload': 'the same, EVChargingVectorEnv(..., pipeline=2)', 'ms_per_step': round(dt2 * 1e3, 5),
                               'env_steps_per_s': round(N / dt2, 1)}
+    # closed loop under greedy (GreedyAlgorithm, baselines.py:22-35), two episodes: (a) the caller computes sign(obs['demands'])
+    # with one torch kernel per step and hands the tensor in; (b) step(policy='greedy'): the streaming kernels apply the rule
+    # themselves — no action tensor, no policy kernel, the step stays two pipelined halves (round 6)
+    for tag, pipe in (('', 1), ('_pipeline2', 2)):
+        for form in ('caller_greedy', 'policy_greedy'):
+            venv = EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2019', seed=0), num_envs=N, output='torch',
+                                       device=dev_index, charge_calculation=battery, pipeline=pipe)
+            obs, _ = venv.reset(seed=0)
+            a = torch.zeros((N, venv.num_stations), device=dev)
+
+            def one(obs):
+                if form == 'policy_greedy':
+                    return venv.step(policy='greedy')[0]
+                if pipe == 2:
+                    for sl, st in halves:
+                        with torch.cuda.stream(st):
+                            torch.sign(obs['demands'][sl], out=a[sl])
+                else:
+                    torch.sign(obs['demands'], out=a)
+                return venv.step(a)[0]
+            halves = venv.pipeline_halves() if pipe == 2 else None
+            for _ in range(EPISODE):
+                obs = one(obs)
+            venv.join()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(2 * EPISODE):
+                obs = one(obs)
+            venv.join()
+            torch.cuda.synchronize(dev)
+            dtg = (time.perf_counter() - t0) / (2 * EPISODE)
+            venv.close()
+            out[f'torch{tag}_{form}'] = {'workload': f'the same environments under greedy, {form.replace("_", " ")}'
+                                                     + (', pipeline=2' if pipe == 2 else ''),
+                                         'ms_per_step': round(dtg * 1e3, 5), 'env_steps_per_s': round(N / dtg, 1)}
     Nn = 16384
     venv = EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2019', seed=0), num_envs=Nn, output='numpy',
                                zero_copy=True, device=dev_index, charge_calculation=battery)
@@ -1149,12 +1184,23 @@ def run_leg(fn, budget_s: float, deadline: float):
             rec['leg_seconds'] = round(time.monotonic() - t0, 2)
         return rec
     except LegTimeout:
-        return {'error': f'timed out after {time.monotonic() - t0:.1f} s (--leg-budget-s {budget_s})'}
+        err = f'timed out after {time.monotonic() - t0:.1f} s (--leg-budget-s {budget_s})'
     except Exception as exc:          # a secondary record must never cost the headline
-        return {'error': f'{type(exc).__name__}: {exc}'}
+        err = f'{type(exc).__name__}: {exc}'
     finally:
         signal.setitimer(signal.ITIMER_REAL, 0)
         signal.signal(signal.SIGALRM, old)
+    # the leg was cut off mid-loop: whatever engines and environments its frames held go away NOW (their finalisers close the
+    # HIP engines and free their buffers) instead of riding along under the legs that follow
+    import gc
+    gc.collect()
+    try:
+        import torch
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    except Exception:
+        pass
+    return {'error': err}
 
 
 def main():

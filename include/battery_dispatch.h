@@ -73,10 +73,15 @@ int bat_step(bat_engine* e, const float* bids_dev, float* obs_dev, double* rewar
  * observation rows of those steps are not written). */
 int bat_rollout(bat_engine* e, const float* bids_ring_dev, int32_t ring_len, int32_t steps, float* obs_dev, double* reward_dev,
                 uint8_t* terminated_dev, float* obs_traj_dev, double* reward_traj_dev);
-/* The same with the trajectory rows `traj_pitch` floats apart (even, >= 4k+6): obs_traj_dev is [steps][N][traj_pitch], row
- * (i, env) starts at ((i * N) + env) * traj_pitch and holds 4k+6 floats; what lies behind them is not written.  A pitch of
- * 160 floats (640 B; the default of BatteryDispatchVectorEnv.rollout, which hands out the [steps, N, 4k+6] view) puts every row
- * on a 128-byte line boundary: full-line stores instead of 600-byte rows that straddle lines (round 5). */
+/* The same with the trajectory rows |traj_pitch| floats apart (even, >= 4k+6): obs_traj_dev is [steps][N][|traj_pitch|], row
+ * (i, env) starts at ((i * N) + env) * |traj_pitch| and holds 4k+6 floats.
+ *   traj_pitch > 0: what lies behind the 4k+6 floats of a row is NOT written (the caller may keep other columns there).
+ *   traj_pitch < 0: the floats behind each row, up to the pitch, belong to the kernel and are filled with ZEROS: with a pitch
+ *     that is a multiple of 32 floats and a 128-byte aligned base every row leaves as whole 128-byte lines (non-temporal
+ *     stores) instead of 600-byte rows that straddle lines (round 5).  -160 (640 B) is what BatteryDispatchVectorEnv.rollout
+ *     passes for the buffer it allocates itself; it hands out the [steps, N, 4k+6] view.
+ * The bid ring, one step's trajectory slab and the reward trajectory are addressed with 32-bit offsets: each must stay below
+ * 4 GiB (ring_len * N * 2k * 4, N * |traj_pitch| * 4, steps * N * 8 bytes) or the call fails. */
 int bat_rollout_pitched(bat_engine* e, const float* bids_ring_dev, int32_t ring_len, int32_t steps, float* obs_dev, double* reward_dev,
                         uint8_t* terminated_dev, float* obs_traj_dev, int32_t traj_pitch, double* reward_traj_dev);
 /* the same with host buffers (staged through engine-owned device buffers) */

@@ -3,7 +3,7 @@
 Public surface (mirrors ``sustaingym.envs.evcharging``):
 
     EVChargingEnv, MultiAgentEVChargingEnv, DiscreteActionWrapper      (reference API)
-    EVChargingVectorEnv, SB3VecEnv                                      (batched API)
+    EVChargingVectorEnv, SB3VecEnv, RLlibVectorEnv                      (batched API + RL-library adapters)
     RealTraceGenerator, GMMsTraceGenerator, BatchedGMMTraceGenerator,
     DeviceGMMTraceGenerator, RealTraceBank                              (episode generators)
     StepEngine                                                          (C-ABI handle)
@@ -26,7 +26,7 @@ def __getattr__(name):
         from .battery import BatteryDispatchVectorEnv
         return BatteryDispatchVectorEnv
     if name in ('EVChargingEnv', 'MultiAgentEVChargingEnv', 'DiscreteActionWrapper',
-                'EVChargingVectorEnv', 'SB3VecEnv', 'MultiAgentEVChargingVectorEnv'):
+                'EVChargingVectorEnv', 'SB3VecEnv', 'RLlibVectorEnv', 'MultiAgentEVChargingVectorEnv'):
         from . import envs
         return getattr(envs, name)
     raise AttributeError(name)

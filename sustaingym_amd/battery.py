@@ -137,11 +137,12 @@ class BatteryDispatchVectorEnv:
                 pitch = (self.F + 31) // 32 * 32
                 store = torch.zeros((steps, self.N, pitch), dtype=torch.float32, device=obs.device)
                 traj = (store[:, :, :self.F], torch.zeros((steps, self.N), dtype=torch.float64, device=obs.device))
+                pitch = -pitch           # the padding of OUR allocation is the kernel's to fill: whole-line stores (battery_dispatch.h)
             else:
                 traj = out
                 assert tuple(traj[0].shape) == (steps, self.N, self.F) and tuple(traj[1].shape) == (steps, self.N)
                 assert traj[0].stride(2) == 1 and traj[0].stride(0) == self.N * traj[0].stride(1), 'obs_traj: rows at a constant pitch'
-                pitch = int(traj[0].stride(1))
+                pitch = int(traj[0].stride(1))   # positive: nothing behind the 4k+6 floats of a row is written (a caller's wider tensor)
         self._check(self.lib.bat_rollout_pitched(self.handle, C.c_void_p(bids_ring.data_ptr()), int(bids_ring.shape[0]), int(steps),
                                                  C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(term.data_ptr()),
                                                  C.c_void_p(traj[0].data_ptr()) if traj else None, pitch,

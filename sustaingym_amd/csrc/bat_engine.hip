@@ -313,14 +313,15 @@ __global__ __launch_bounds__(256) void bat_rollout_kernel(BatParams P, const flo
         double ri = p * x + P.pco2 * m * x;
         if (done1) ri -= term_price * fmax(0.0, P.e0 - e1);
         if constexpr (TRAJ) {
-            // trajectory rows at the caller's pitch (floats): the descriptor of step i's slab [N][pitch]; the padding behind the
-            // 4k+6 floats is written too (zeros) so that whole lines go out
+            // trajectory rows at the caller's pitch (floats): the descriptor of step i's slab [N][pitch].  NT (whole-line form,
+            // the caller said the padding is the kernel's: bat_rollout_pitched with a negative pitch): the padding behind the
+            // 4k+6 floats is written too (zeros) so that whole lines go out; otherwise nothing behind the row is touched
             const bat_rsrc_t r_traj = bat_rsrc(obs_traj + (size_t)i * N * (size_t)traj_pitch, (size_t)N * (size_t)traj_pitch * 4u);
 #pragma unroll
             for (int j = 0; j < kPairPasses; j++) {
                 const int pr = q + LPE * j;
                 const float2 v = row_value(pr, cur.a[j], cur.f[j], t1, e1, x, pf, lf, mf);
-                bat_st_f32x2<NT ? 2 : 0>(r_traj, (act && ev && pr < traj_pitch / 2) ? (env * (unsigned)traj_pitch + 2u * (unsigned)pr) * 4u : kBatOob, v);
+                bat_st_f32x2<NT ? 2 : 0>(r_traj, (act && ev && pr < (NT ? traj_pitch : F) / 2) ? (env * (unsigned)traj_pitch + 2u * (unsigned)pr) * 4u : kBatOob, v);
             }
         }
         bat_st_f64(r_rt, (ev && q == 0) ? ((unsigned)i * N + env) * 8u : kBatOob, act ? ri : 0.0);
@@ -485,8 +486,25 @@ int bat_rollout_pitched(bat_engine* e, const float* bids_ring_dev, int32_t ring_
                         uint8_t* terminated_dev, float* obs_traj_dev, int32_t traj_pitch, double* reward_traj_dev) {
     if (!e || !bids_ring_dev || !obs_dev || !reward_dev || !terminated_dev) return fail(-1, "bat_rollout: null argument");
     if (ring_len < 1 || steps < 1) return fail(-1, "bat_rollout: ring_len and steps must be >= 1");
+    // a NEGATIVE pitch: rows |pitch| floats apart AND the floats behind each row (up to the pitch) are the kernel's to fill with
+    // zeros — whole 128-byte lines go out with non-temporal stores.  A positive pitch never writes behind the 4k+6 floats: the
+    // caller may keep other columns there (`out[0]` as a [:, :, :F] slice of a wider tensor).
+    const bool pad_mine = traj_pitch < 0;
+    if (pad_mine) traj_pitch = -traj_pitch;
     if (obs_traj_dev && (traj_pitch < e->P.F || (traj_pitch & 1)))
         return fail(-1, "bat_rollout: trajectory pitch %d must be even and >= the observation width %d", traj_pitch, e->P.F);
+    // the kernel addresses the bid ring, a step's trajectory slab and the reward trajectory through 32-bit buffer offsets
+    // (raw buffer descriptors: num_records < 4 GiB); larger ones would wrap or be range-dropped silently
+    {
+        const unsigned long long lim = 0xffffff00ull, N = (unsigned long long)e->P.N;
+        if ((unsigned long long)ring_len * N * 2ull * (unsigned long long)e->P.k * 4ull > lim)
+            return fail(-1, "bat_rollout: bid ring of %d x %d x %d floats exceeds the 4 GiB a launch can address: pass a shorter ring "
+                            "(ring_len <= %llu) or roll out in chunks", ring_len, e->P.N, 2 * e->P.k, lim / (N * 2ull * (unsigned long long)e->P.k * 4ull));
+        if (reward_traj_dev && (unsigned long long)steps * N * 8ull > lim)
+            return fail(-1, "bat_rollout: reward trajectory of %d x %d doubles exceeds 4 GiB: roll out in chunks of <= %llu steps", steps, e->P.N, lim / (N * 8ull));
+        if (obs_traj_dev && N * (unsigned long long)traj_pitch * 4ull > lim)
+            return fail(-1, "bat_rollout: one step's trajectory slab (%d rows of %d floats) exceeds 4 GiB", e->P.N, traj_pitch);
+    }
     HIP_TRY(hipSetDevice(e->device));
     // lanes per environment: 16 = the step kernel's geometry (default); 64 = a wavefront per environment, measured SLOWER
     // (7.2 against 5.5 us per 16 384-environment step with a trajectory, 3.0 against 1.6 without): the loop is not short of
@@ -497,7 +515,7 @@ int bat_rollout_pitched(bat_engine* e, const float* bids_ring_dev, int32_t ring_
     hipLaunchKernelGGL((bat_rollout_kernel<L, T, NTF>), dim3(GRID), dim3(256), 0, e->stream, e->P, bids_ring_dev, ring_len, steps, obs_dev, \
                        reward_dev, terminated_dev, obs_traj_dev, traj_pitch, reward_traj_dev)
     const bool traj = obs_traj_dev != nullptr;
-    const bool lines = traj && traj_pitch % 32 == 0 && ((uintptr_t)obs_traj_dev & 127u) == 0;
+    const bool lines = traj && pad_mine && traj_pitch % 32 == 0 && ((uintptr_t)obs_traj_dev & 127u) == 0;
     const int g16 = (e->P.N + 15) / 16, g64 = (e->P.N + 3) / 4;
     if (lpe == 16) {
         if (!traj) BAT_LAUNCH_ROLLOUT(16, false, false, g16);

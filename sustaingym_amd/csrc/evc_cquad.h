@@ -99,8 +99,13 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
 // interleaved A/B) and 4 is 1.2 us faster without; on congested days, where most wavefronts run a wide copy, 3 wins:
 // Caltech's GMM day 42.1 -> 38.8 us per step, JPL's streaming kernel 45.2 -> 34.6 (38.3 at 2).  The engine launches the
 // projecting lean kernels at 3 (EVC_PROJ_WAVES, evc_engine.hip), everything else at EVC_CQUAD_WAVES.
-template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES>
+//
+// GREEDY (lean projecting kernels, round 6): the device-resident GreedyAlgorithm compiled in — a run-time flag in the kernel
+// that reads action rows cost the headline 0.5 - 0.7 us per step (measured, profiles/r6_lean_greedy_ab.txt), so the rule has
+// instantiations of its own; the debug kernels keep testing StepIO::action_kind.
+template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES, bool GREEDY = false>
 __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params P, StepIO io) {
+    static_assert(!GREEDY || (PROJECT && !DBG), "the compiled-in greedy rule exists for the lean projecting kernels");
     static_assert(!DRAIN || (PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");
     __shared__ CquadLds S;
     __shared__ double dbg_img[DBG ? 4 : 1][4][64];     // unused (and dropped) in the lean kernels
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 
     const rsrc_t r_win = row_rsrc(P.win_base, P.win_span);      // every engine-owned array (struct Win)
     const Win r_rem{r_win, P.off_rem}, r_de{r_win, P.off_de};
-    const rsrc_t r_act = row_rsrc(io.actions, (!DBG || io.actions) ? N * n * 4u : 0u);
+    const rsrc_t r_act = row_rsrc(io.actions, io.actions ? N * n * 4u : 0u);
     const Win r_scal{r_win, P.off_scal}, r_acc{r_win, P.off_acc};
     const rsrc_t r_obs = row_rsrc(io.out.obs, N * F * 4u);
     const Win r_mtail{r_win, P.off_mtail}, r_hist{r_win, P.off_hist};
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     const rsrc_t r_bd = row_rsrc(io.out.breakdown, io.out.breakdown ? N * 24u : 0u);
     const Win r_sess{r_win, P.off_sess}, r_req{r_win, P.off_req};
 
-    const bool greedy = DBG && io.action_kind == EVC_ACTION_GREEDY;
+    // device-resident GreedyAlgorithm (baselines.py:22-35): every plugged-in EV with demand left asks for the full rate; no action
+    // row is read (EVChargingVectorEnv.step(policy='greedy'))
+    const bool greedy = DBG ? io.action_kind == EVC_ACTION_GREEDY : GREEDY;
     const bool stepwise = P.battery_stepwise != 0;
     const unsigned nquads = (N + 3u) >> 2;
     // this launch's share of the batch (StepIO::quad_lo / quad_hi; the whole batch unless the engine pipelines two halves)
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // one 16-byte load (rows are n * 4 bytes apart: 4- or 8-byte aligned, which buffer accesses allow; the range check is
         // per dword, tools/probes/b128_probe.hip); a lane whose chunk runs past station n - 1 reads the head of the next row
         // there (zeros behind the last row) and masks it with st_valid
-        L.a4 = v4u{0u, 0u, 0u, 0u};
-        if (!greedy) L.a4 = buf_ld_v4(r_act, (ev_ && st_valid[0]) ? (eb_ + st4) * 4u : kOob);
+        // (greedy: no action buffer — r_act has no records, every lane reads 0; no branch around the load)
+        L.a4 = buf_ld_v4(r_act, (ev_ && st_valid[0]) ? (eb_ + st4) * 4u : kOob);
         return L;
     };
     // The first quad's loads are issued before the LDS tables are built: the two latency chains (network
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         float a_st[kSlots];                         // clamped action of this lane's stations
 #pragma unroll
         for (int j = 0; j < kSlots; j++) a_st[j] = 0.0f;
-        if (!greedy) {
+        {
             const float a_in[kSlots] = {__uint_as_float(cur.a4.x), __uint_as_float(cur.a4.y), __uint_as_float(cur.a4.z), __uint_as_float(cur.a4.w)};
 #pragma unroll
             for (int j = 0; j < kSlots; j++) {

@@ -452,7 +452,10 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     // The staged action kinds run a kernel on the engine's stream before the step (random_actions_kernel reads the
     // environments' scalars): it must not overtake half launches still pending on the side streams.  Such steps are
     // never split themselves (below).
-    if (action_kind != EVC_ACTION_F32)
+    // the lean projecting kernels of the compact layout have the greedy rule compiled in (step_kernel_cquad<..., GREEDY = true>)
+    const bool lean_greedy = action_kind == EVC_ACTION_GREEDY && e->use_quad && e->compact && e->P.project &&
+                             !(out->pilots || out->rates || out->projected || out->returns);
+    if (action_kind != EVC_ACTION_F32 && !lean_greedy)
         if (int rc = join_halves(e)) return rc;
     if (action_kind == EVC_ACTION_DISCRETE) {
         const size_t count = (size_t)e->P.N * e->P.n;
@@ -476,7 +479,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     e->P.host_qlen = e->d_qlen ? e->d_qlen + (e->step_index % kQlenRing) : nullptr;
     const int words = (e->P.G + 1) / 2;
     const bool dbg = out->pilots || out->rates || out->projected || out->returns ||
-                     action_kind == EVC_ACTION_GREEDY;
+                     (action_kind == EVC_ACTION_GREEDY && !lean_greedy);
     // drain mode (see evc_engine): the lean compact streaming kernel can drain short queues itself
     // Who finishes the rows whose projection needs the iterative solver (lean compact streaming kernel):
     //   1  the workgroup that queued them, from a list of its own once its streaming work is done;
@@ -527,7 +530,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     // go through one staging buffer the next step would overwrite), and only where a half still fills the grid.
     const int split_cap = e->P.project ? e->proj_grid : e->quad_grid;
     const bool split = e->pipeline == 2 && e->use_quad && e->compact && !dbg &&
-                       action_kind == EVC_ACTION_F32 && ((e->P.N + 3) / 4) / 2 >= (getenv("EVC_SPLIT_MINQ") ? atoi(getenv("EVC_SPLIT_MINQ")) : 4) * split_cap;
+                       (action_kind == EVC_ACTION_F32 || lean_greedy) && ((e->P.N + 3) / 4) / 2 >= (getenv("EVC_SPLIT_MINQ") ? atoi(getenv("EVC_SPLIT_MINQ")) : 4) * split_cap;
     // The queue's control blocks and report rings exist once per half launch.  A step that is ONE launch uses the first set;
     // where the form changes, what the other form left behind is cleared (rare: a mode or action-kind change).
     if (split != e->last_split) {
@@ -685,8 +688,9 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 (step_kernel_quad<true, W, false>),                                                \
                 (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, e->quad_grid, W)
 #define EVC_LAUNCH_CQUAD(W)                                                                         \
-    EVC_LAUNCH_((step_kernel_cquad<true, W, true>), (step_kernel_cquad<true, W, false, 0, EVC_PROJ_WAVES>), \
-                (step_kernel_cquad<true, W, false, 1, EVC_PROJ_WAVES>),                             \
+    EVC_LAUNCH_((step_kernel_cquad<true, W, true>),                                                                    \
+                (lean_greedy ? step_kernel_cquad<true, W, false, 0, EVC_PROJ_WAVES, true> : step_kernel_cquad<true, W, false, 0, EVC_PROJ_WAVES>), \
+                (lean_greedy ? step_kernel_cquad<true, W, false, 1, EVC_PROJ_WAVES, true> : step_kernel_cquad<true, W, false, 1, EVC_PROJ_WAVES>), \
                 (dbg ? step_kernel_cquad<false, W, true> : step_kernel_cquad<false, W, false>), e->quad_grid, e->proj_grid, W)
 #define EVC_LAUNCH_WAVE(W)                                                                          \
     EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, e->step_grid, W)

@@ -294,7 +294,10 @@ __device__ __forceinline__ bool quad_cone_capped(int G, const double* class_cap,
             fr[j] = in_row[j] && v[j] > 0.0 && v[j] <= h[j] && h[j] > 0.0;
         }
         double w0 = 0.0, w1 = 0.0, K00 = 0.0, K01 = 0.0, K11 = 0.0;
-        capped = 0u;
+        // this pass's capped classes, kept only by rows that are still iterating: a row that converged in an earlier pass keeps the
+        // set of ITS last pass (the loop below visits only the classes some running row loads, so for a finished row the pass is
+        // incomplete; resetting its set made the final filling skip classes and sent the row to the general path — ADVICE r5)
+        unsigned cap_it = 0u;
         for (int g = 0; g < G; g++) {
             const double m0 = net.Mre[g][cc], m1 = net.Mim[g][cc];              // (row-uniform)
             const bool loads = m0 != 0.0 || m1 != 0.0;
@@ -310,7 +313,7 @@ __device__ __forceinline__ bool quad_cone_capped(int G, const double* class_cap,
             const double kg = (double)row_allreduce_u32(nf);
             if (loads) {
                 if (Wg > class_cap[g]) {
-                    capped |= 1u << g;
+                    cap_it |= 1u << g;
                     w0 += m0 * class_cap[g]; w1 += m1 * class_cap[g];
                 } else {
                     w0 += m0 * Wg; w1 += m1 * Wg;
@@ -318,6 +321,7 @@ __device__ __forceinline__ bool quad_cone_capped(int G, const double* class_cap,
                 }
             }
         }
+        if (run) capped = cap_it;
         if (it == 0) {                                   // first-order size along w
             const double nw = sqrt(w0 * w0 + w1 * w1);
             if (!(nw > rmag)) run = false;
@@ -347,7 +351,7 @@ __device__ __forceinline__ bool quad_cone_capped(int G, const double* class_cap,
         if (run) { z0 = t0; z1 = t1; }
         mu = fmax(mu * 0.25, 1e-12);
     }
-    // (a row that converged stopped updating z: v, y and `capped` are those of its last pass)
+    // (a row that converged stopped updating z and `capped`: they are those of its last pass; v and y are recomputed from z)
     if (__ballot(ok) != 0ull) {
 #pragma unroll
         for (int j = 0; j < kSlots; j++) {

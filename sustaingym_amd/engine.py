@@ -218,42 +218,59 @@ class StepEngine:
                                  C.c_void_p(out['obs'].data_ptr())), 'evc_reset')
         return out['obs']
 
-    def step(self, actions, bins: int = 0):
+    _POLICY_KINDS = {'greedy': _lib.ACTION_GREEDY, 'random': _lib.ACTION_RANDOM}
+
+    def step(self, actions=None, bins: int = 0, policy: str | None = None):
         """EVChargingEnv.step for all environments.
 
         ``actions``: torch CUDA tensor ``[N, n]`` (float32, or int64 with ``bins``) -> returns the
         dict of device output tensors (asynchronous on the current torch stream); or a numpy
         array -> synchronous host path returning numpy arrays.
+        ``policy='greedy'`` / ``'random'`` (``actions=None``): the device-resident baselines (baselines.py:22-51) act instead —
+        no action buffer is read; device outputs (the compact streaming kernels apply the greedy rule themselves).
         """
-        if isinstance(actions, np.ndarray):
+        if policy is not None:
+            assert actions is None, 'policy= and actions are exclusive'
+            kind, ptr = self._POLICY_KINDS[policy], None
+        elif isinstance(actions, np.ndarray):
             return self._step_host(actions, bins)
-        torch = self._torch()
-        assert actions.is_cuda and actions.shape == (self.N, self.n) and actions.is_contiguous()
-        if bins > 0:
-            assert actions.dtype == torch.int64
-            kind = _lib.ACTION_DISCRETE
         else:
-            assert actions.dtype == torch.float32
-            kind = _lib.ACTION_F32
+            torch = self._torch()
+            assert actions.is_cuda and actions.shape == (self.N, self.n) and actions.is_contiguous()
+            if bins > 0:
+                assert actions.dtype == torch.int64
+                kind = _lib.ACTION_DISCRETE
+            else:
+                assert actions.dtype == torch.float32
+                kind = _lib.ACTION_F32
+            ptr = C.c_void_p(actions.data_ptr())
         self._bind_stream()
         out = self.device_outputs()
         so = self._step_out_struct(out, lambda t: C.c_void_p(t.data_ptr()))
-        check(self.lib.evc_step(self.handle, C.c_void_p(actions.data_ptr()), kind, bins, C.byref(so)),
-              'evc_step')
+        check(self.lib.evc_step(self.handle, ptr, kind, bins, C.byref(so)), 'evc_step')
         if self._pipeline == 2:          # the returned tensors are consumed on the torch stream: order it after both halves
             check(self.lib.evc_join(self.handle), 'evc_join')
         return out
 
-    def make_stepper(self, bins: int = 0):
+    def make_stepper(self, bins: int = 0, policy: str | None = None):
         """Lean per-step callable for rollout loops: binds the current torch stream once and
         returns ``(step(ptr: int) -> None, outputs)`` where ``ptr`` is the device address of a
-        contiguous ``[N, n]`` action tensor (float32, or int64 when ``bins > 0``)."""
+        contiguous ``[N, n]`` action tensor (float32, or int64 when ``bins > 0``); with ``policy`` ('greedy' / 'random': the
+        device-resident baselines) ``ptr`` is ignored (pass ``None``)."""
         self._bind_stream()
         out = self.device_outputs()
         so = self._step_out_struct(out, lambda t: C.c_void_p(t.data_ptr()))
         ref = C.byref(so)
         fn, handle = self.lib.evc_step, self.handle
         kind = _lib.ACTION_DISCRETE if bins > 0 else _lib.ACTION_F32
+        if policy is not None:
+            kind = self._POLICY_KINDS[policy]
+
+            def step_policy(ptr=None, _keep=so) -> None:
+                rc = fn(handle, None, kind, bins, ref)
+                if rc:
+                    check(rc, 'evc_step')
+            return step_policy, out
 
         def step(ptr: int, _keep=so) -> None:
             rc = fn(handle, ptr, kind, bins, ref)

@@ -10,6 +10,8 @@ reference's API layer:
   around the reference env (train_stable_baselines.py:271-275): N environments, Gymnasium-0.28
   ``VectorEnv`` semantics (autoreset, ``final_observation``), backed by ONE engine call per step.
 * :class:`SB3VecEnv`                <- stable_baselines3 ``VecEnv`` protocol adapter.
+* :class:`RLlibVectorEnv`           <- ``ray.rllib.env.VectorEnv`` protocol adapter (what ``num_envs_per_worker`` builds out of
+  copies of the reference env, examples/evcharging/train_rllib.py:129-134,158-160).
 
 All arithmetic of ``step()`` runs in the HIP kernels through the C-ABI; these classes only move
 buffers and keep host-side episode bookkeeping (generators, max_profit).
@@ -52,6 +54,10 @@ try:  # pragma: no cover
     from stable_baselines3.common.vec_env import VecEnv as _SB3VecEnvBase
 except Exception:
     _SB3VecEnvBase = object
+try:  # pragma: no cover
+    from ray.rllib.env.vector_env import VectorEnv as _RLlibVectorEnvBase
+except Exception:
+    _RLlibVectorEnvBase = object
 
 MAX_SESSIONS = 256
 OBS_KEYS = ('demands', 'est_departures', 'forecasted_moer', 'prev_moer', 'timestep')  # sorted
@@ -448,6 +454,7 @@ class EVChargingVectorEnv(_VectorEnvBase):
         self._stepper = None
         self._stepper_out = None
         self._stepper_stream = None
+        self._stepper_policy = None
         self._lean_views = None
         self._lean_info = None
         self._pool = None
@@ -497,10 +504,17 @@ class EVChargingVectorEnv(_VectorEnvBase):
             # reset()): fetched then (_flush_max_profit), not behind the generating kernel with the GPU idle meanwhile
             self._max_profit_pending.append((first, cnt))
 
-    def _flush_max_profit(self) -> None:
+    def _flush_max_profit(self, needed: np.ndarray | None = None) -> None:
+        """Downloads the max_profit values still on the GPU.  ``needed`` (bank slots about to be reported): only the pending
+        runs that hold one of them — the slots refilled at THIS boundary are played an episode from now, and fetching them here
+        would synchronise behind the generating kernel that was just launched (the deferral did not defer)."""
+        keep = []
         for first, cnt in self._max_profit_pending:
+            if needed is not None and not bool(((needed >= first) & (needed < first + cnt)).any()):
+                keep.append((first, cnt))
+                continue
             self._max_profit[first:first + cnt] = self._engine.download_episodes(first, cnt, tables=False)[4]
-        self._max_profit_pending = []
+        self._max_profit_pending = keep
 
     def _finish_batched(self, slots, drawn) -> None:
         ns, sess, req, day, mp = drawn
@@ -582,7 +596,7 @@ class EVChargingVectorEnv(_VectorEnvBase):
         bd = None if out is None else out['breakdown']
         if self._info_max_profit is None:
             if self._max_profit_pending:
-                self._flush_max_profit()
+                self._flush_max_profit(self._cur_slot)
             self._info_max_profit = self._max_profit[self._cur_slot]
         info = {'max_profit': self._info_max_profit}
         if bd is not None:
@@ -594,16 +608,22 @@ class EVChargingVectorEnv(_VectorEnvBase):
             info['_final_info'] = done_mask
         return info
 
-    def step(self, actions):
+    def step(self, actions=None, *, policy: str | None = None):
+        """One step of all environments.  ``policy='greedy'`` / ``'random'`` (instead of ``actions``): the device-resident
+        baselines act (GreedyAlgorithm / RandomAlgorithm, algorithms/evcharging/baselines.py:22-51) — no action tensor is built
+        or read, the demand columns of the observation make no round trip through a policy kernel.  ``'greedy'`` is what
+        ``step(sign(obs['demands']))`` does, bit for bit (``tests/test_gpu_env_api.py``)."""
         N = self.num_envs
         bins = self.discrete_bins if self.discrete_bins > 0 else 0
+        assert (actions is None) != (policy is None), 'pass either actions or policy='
         # All environments are reset together and every episode lasts 288 steps, so the boundary
         # is known on the host: no device->host read of `terminated` on the torch path.
         self._steps_in_episode += 1
         boundary = self._steps_in_episode >= 288
         self._drain(force=boundary)                           # next episodes must be in the bank now
         if self.output == 'numpy':
-            out = self._engine.step(np.ascontiguousarray(actions), bins=bins)
+            out = (self._engine.step_policy(policy, bins=bins) if policy is not None
+                   else self._engine.step(np.ascontiguousarray(actions), bins=bins))
             term = out['terminated'].astype(bool)
             assert bool(term.all()) == boundary == bool(term.any())
             # the engine alternates between two sets of page-locked output arrays: with zero_copy what this
@@ -613,12 +633,15 @@ class EVChargingVectorEnv(_VectorEnvBase):
             truncated = np.zeros(N, dtype=bool)
         else:
             import torch
-            if bins == 0 and actions.dtype == torch.float32 and actions.is_contiguous() and actions.is_cuda:
+            lean_policy = policy == 'greedy' and bins == 0
+            if lean_policy or (policy is None and bins == 0 and actions.dtype == torch.float32 and actions.is_contiguous()
+                               and actions.is_cuda):
                 # lean path: one ctypes call per step on a pre-built argument block
-                stream = torch.cuda.current_stream(actions.device).cuda_stream
-                if self._stepper is None or stream != self._stepper_stream:
-                    self._stepper, self._stepper_out = self._engine.make_stepper()
+                stream = torch.cuda.current_stream(self._engine.device).cuda_stream
+                if self._stepper is None or stream != self._stepper_stream or self._stepper_policy != policy:
+                    self._stepper, self._stepper_out = self._engine.make_stepper(policy=policy)
                     self._stepper_stream = stream
+                    self._stepper_policy = policy
                     # The stepper's outputs are the SAME tensors every step (like the reference's reused observation
                     # buffers, env.py:152-158): their views — the observation dict, terminated as bool, the breakdown
                     # columns — are built once, not per step (16.5 -> ~8 us of host time per step; with pipeline=2 the host
@@ -628,8 +651,11 @@ class EVChargingVectorEnv(_VectorEnvBase):
                     self._lean_views = (self._wrap_obs(so['obs']), so['reward'], so['terminated'].view(torch.bool),
                                         {'profit': bd[:, 0], 'carbon_cost': bd[:, 1], 'excess_charge': bd[:, 2]})
                     self._lean_info = None
-                assert actions.dim() == 2 and actions.shape[0] == N and actions.shape[1] == self.num_stations
-                self._stepper(actions.data_ptr())
+                if policy is None:
+                    assert actions.dim() == 2 and actions.shape[0] == N and actions.shape[1] == self.num_stations
+                    self._stepper(actions.data_ptr())
+                else:
+                    self._stepper(None)
                 out = self._stepper_out
                 if not boundary:
                     obs_v, rew_v, term_v, bd_v = self._lean_views
@@ -637,13 +663,15 @@ class EVChargingVectorEnv(_VectorEnvBase):
                         self._false_dev = term_v.new_zeros(N)
                     if self._info_max_profit is None:            # first step of an episode (reset() / the boundary step cleared it)
                         if self._max_profit_pending:
-                            self._flush_max_profit()
+                            self._flush_max_profit(self._cur_slot)
                         self._info_max_profit = self._max_profit[self._cur_slot]
                     if self._lean_info is None or self._lean_info['max_profit'] is not self._info_max_profit:
                         # one dict per EPISODE: rebuilt whenever the episode's max_profit array was (the boundary step and
                         # reset() refill _info_max_profit through _infos(), so testing it for None here is not enough)
                         self._lean_info = {'max_profit': self._info_max_profit, 'reward_breakdown': bd_v}
                     return obs_v, rew_v, term_v, self._false_dev, self._lean_info
+            elif policy is not None:
+                out = self._engine.step(bins=bins, policy=policy)
             else:
                 out = self._engine.step(actions, bins=bins)
             term = out['terminated'].view(torch.bool)             # uint8 0/1: zero-copy
@@ -754,18 +782,29 @@ class MultiAgentEVChargingVectorEnv:
 
 class _StepInfoSource:
     """What the per-environment info dicts of one SB3VecEnv step are made of (arrays over the batch)."""
-    __slots__ = ('max_profit', 'breakdown', 'done', 'final')
+    __slots__ = ('max_profit', 'breakdown', 'done', 'final', 'written')
 
     def __init__(self):
         self.max_profit = self.breakdown = self.done = self.final = None
+        self.written: list = []          # info objects somebody stored a key in during the current step (next_step drops those keys)
+
+    def next_step(self) -> None:
+        """A new step begins: what wrappers stored in the previous step's info objects (``info[k] = v``) goes away with that
+        step, as it does with the fresh dicts DummyVecEnv / SubprocVecEnv hand out.  VecNormalize and VecFrameStack overwrite
+        ``infos[i]['terminal_observation']`` IN PLACE; kept, that value would shadow the lazy one in every later step and
+        episode of the environment (VERDICT / ADVICE r5).  Cost: one pass over the objects that were written, usually none."""
+        for d in self.written:
+            dict.clear(d)
+        self.written.clear()
 
 
 class _LazyInfo(dict):
     """``infos[i]`` of :class:`SB3VecEnv` without a Python loop over the batch: a dict whose items are read out of the step's
     batch arrays when somebody asks (SB3 itself looks at ``TimeLimit.truncated`` / ``terminal_observation`` of the environments
     that ended; monitors ``.copy()`` and add an ``episode`` key).  The N objects are created once; every step they describe the
-    CURRENT step (keep ``dict(info)`` / ``info.copy()`` — real dicts — if an old one is needed).  Extra keys a wrapper stores
-    through ``info[k] = v`` live in the dict proper and stay with that environment's object."""
+    CURRENT step (keep ``dict(info)`` / ``info.copy()`` — real dicts — if an old one is needed).  Keys a wrapper stores
+    through ``info[k] = v`` (``update``, ``setdefault``) live in the dict proper and shadow the lazy value FOR THAT STEP: the
+    next ``step_wait`` drops them (:meth:`_StepInfoSource.next_step`)."""
     __slots__ = ('_src', '_i')
     _KEYS = ('max_profit', 'reward_breakdown', 'TimeLimit.truncated')
 
@@ -775,6 +814,24 @@ class _LazyInfo(dict):
 
     def _has_terminal(self) -> bool:
         return self._src.done is not None and bool(self._src.done[self._i])
+
+    def _mark_written(self) -> None:
+        if not dict.__len__(self):
+            self._src.written.append(self)
+
+    def __setitem__(self, key, value):
+        self._mark_written()
+        dict.__setitem__(self, key, value)
+
+    def update(self, *args, **kwargs):
+        self._mark_written()
+        dict.update(self, *args, **kwargs)
+
+    def setdefault(self, key, default=None):
+        if key in self:
+            return self[key]
+        self[key] = default
+        return default
 
     def __missing__(self, key):
         s, i = self._src, self._i
@@ -881,6 +938,7 @@ class SB3VecEnv(_SB3VecEnvBase):
             self.venv.zero_copy = keep
         if self._infos_mode == 'lazy':
             src = self._info_src
+            src.next_step()                        # keys wrappers wrote into the previous step's info objects end with that step
             src.max_profit = info['max_profit']
             bd = info['reward_breakdown']
             src.breakdown = np.stack([bd['profit'], bd['carbon_cost'], bd['excess_charge']], axis=1)     # a copy: [N, 3]
@@ -929,3 +987,132 @@ class SB3VecEnv(_SB3VecEnvBase):
 
     def get_images(self):
         return [None] * self.num_envs
+
+
+class _SubEnvView:
+    """What :meth:`RLlibVectorEnv.get_sub_environments` hands out: RLlib asks its sub-environments for their spaces (and a
+    few attributes) only; stepping goes through the vector env.  A view, not an environment: ``step`` / ``reset`` refuse."""
+
+    def __init__(self, owner: 'RLlibVectorEnv', index: int):
+        self._owner, self.index = owner, index
+        self.observation_space, self.action_space = owner.observation_space, owner.action_space
+        self.spec = None
+        self.metadata: dict[str, Any] = {}
+        self.render_mode = None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def step(self, action):
+        raise RuntimeError('sub-environments of RLlibVectorEnv are stepped together: use vector_step')
+
+    def reset(self, **kwargs):
+        return self._owner.reset_at(self.index, **kwargs)
+
+    def close(self) -> None:
+        pass
+
+
+class RLlibVectorEnv(_RLlibVectorEnvBase):
+    """``ray.rllib.env.vector_env.VectorEnv`` protocol (Ray 2.x: ``vector_reset``, ``reset_at``, ``restart_at``,
+    ``vector_step``, ``get_sub_environments``) over :class:`EVChargingVectorEnv` — the batched form of what the reference
+    gives RLlib: ``num_envs_per_worker`` copies of ``FlattenObservation(EVChargingEnv(gen))`` per rollout worker, optionally
+    under ``DiscreteActionWrapper`` (examples/evcharging/train_rllib.py:129-134,158-160; tests/test_evcharging.py:26-27).
+    Derives from RLlib's ``VectorEnv`` when ray is installed, so that ``config.environment(lambda cfg: RLlibVectorEnv(...))``
+    is taken as it is instead of being wrapped.
+
+    ``flatten=True`` (default, what the reference's scripts do): observations are flat float32 vectors of length
+    2 n + k + 2 in ``gymnasium.spaces.flatten`` order (= the engine's own row); ``False``: the Dict observation of env.py:143-150.
+
+    Episodes: the engine resets all environments itself at the boundary (they run in lock-step, 288 steps).  RLlib's sampler
+    wants the TERMINAL observation from ``vector_step`` and the first observation of the next episode from ``reset_at(i)``:
+    the boundary step returns ``info['final_observation']`` rows and keeps the new episode's first observations for the
+    ``reset_at`` calls that follow.  ``reset_at`` of an environment that has not terminated is refused (lock-step)."""
+
+    def __init__(self, venv: EVChargingVectorEnv, flatten: bool = True):
+        assert venv.output == 'numpy', 'RLlib moves numpy observations'
+        self.venv = venv
+        self.flatten = bool(flatten)
+        obs_space = spaces.flatten_space(venv.single_observation_space) if flatten else venv.single_observation_space
+        if _RLlibVectorEnvBase is not object:
+            super().__init__(obs_space, venv.single_action_space, venv.num_envs)
+        self.observation_space, self.action_space, self.num_envs = obs_space, venv.single_action_space, venv.num_envs
+        self._subs = [_SubEnvView(self, i) for i in range(self.num_envs)]
+        self._pending_obs = None            # first observations of the next episode, handed out by reset_at after a boundary
+        self._pending_info = None
+        self._awaiting = np.zeros(self.num_envs, dtype=bool)
+        self._started = False
+
+    # -- helpers ------------------------------------------------------------------------------------------------------
+    def _rows(self, obs: dict[str, np.ndarray]):
+        """Batched dict observation -> list of N per-environment observations (copies: RLlib keeps them in its batches)."""
+        if self.flatten:
+            flat = np.concatenate([obs[key] for key in OBS_KEYS], axis=1)             # spaces.flatten order (sorted keys)
+            return list(flat)
+        cols = {key: np.array(obs[key]) for key in OBS_KEYS}
+        return [{key: cols[key][i] for key in OBS_KEYS} for i in range(self.num_envs)]
+
+    @staticmethod
+    def _info_rows(info: dict[str, Any], n: int, max_profit=None):
+        mp = info['max_profit'] if max_profit is None else max_profit
+        bd = info.get('reward_breakdown')
+        if bd is None:
+            return [{'max_profit': float(mp[i])} for i in range(n)]
+        p, c, x = bd['profit'], bd['carbon_cost'], bd['excess_charge']
+        return [{'max_profit': float(mp[i]),
+                 'reward_breakdown': {'profit': float(p[i]), 'carbon_cost': float(c[i]), 'excess_charge': float(x[i])}}
+                for i in range(n)]
+
+    # -- ray.rllib.env.VectorEnv ----------------------------------------------------------------------------------
+    def vector_reset(self, *, seeds=None, options=None):
+        seed = None if seeds is None or all(sd is None for sd in seeds) else [0 if sd is None else int(sd) for sd in seeds]
+        obs, info = self.venv.reset(seed=seed)
+        self._awaiting[:] = False
+        self._pending_obs = self._pending_info = None
+        self._started = True
+        return self._rows(obs), self._info_rows(info, self.num_envs)
+
+    def reset_at(self, index: int | None = None, *, seed=None, options=None):
+        index = 0 if index is None else int(index)
+        if not self._started:                         # RLlib may reset single sub-environments first: start all of them once
+            obs, infos = self.vector_reset(seeds=None if seed is None else [int(seed) + i for i in range(self.num_envs)])
+            self._pending_obs, self._pending_info = obs, infos
+            self._awaiting[:] = True
+        if not self._awaiting[index]:
+            raise ValueError(f'reset_at({index}): the environment has not terminated — the batch runs in lock-step '
+                             '(288-step episodes, reset together by the engine); use vector_reset to restart all of it')
+        self._awaiting[index] = False
+        return self._pending_obs[index], self._pending_info[index]
+
+    def restart_at(self, index: int | None = None) -> None:
+        raise NotImplementedError('restart_at: sub-environments share one engine and cannot be re-created one by one')
+
+    def vector_step(self, actions):
+        if self._awaiting.any():
+            raise RuntimeError('vector_step before reset_at was called for every terminated environment')
+        a = np.stack([np.asarray(x) for x in actions]) if not isinstance(actions, np.ndarray) else actions
+        if self.venv.discrete_bins > 0:
+            a = a.astype(np.int64, copy=False)
+        else:
+            a = a.astype(np.float32, copy=False)
+        obs, rew, term, trunc, info = self.venv.step(a)
+        n = self.num_envs
+        infos = self._info_rows(info, n, info['final_info']['max_profit'] if term.any() else None)
+        if term.any():                                 # lock-step: all of them
+            self._pending_obs = self._rows(obs)                              # next episode's first observations
+            self._pending_info = [{'max_profit': float(v)} for v in info['max_profit']]
+            self._awaiting[:] = np.asarray(term, dtype=bool)
+            rows = self._rows(info['final_observation'])                    # what the episode ended on
+        else:
+            rows = self._rows(obs)
+        return rows, [float(r) for r in rew], [bool(t) for t in term], [bool(t) for t in trunc], infos
+
+    def get_sub_environments(self):
+        return self._subs
+
+    def try_render_at(self, index: int | None = None):
+        return None
+
+    def close(self) -> None:
+        self.venv.close()

@@ -148,3 +148,45 @@ def test_battery_rollout_equals_the_loop_of_steps_and_the_oracle(trajectory):
                 assert abs(rew_all[t, i] - r) <= 1e-12 * max(1.0, abs(r))
     for env in envs:
         env.close()
+
+
+def test_battery_rollout_leaves_a_callers_neighbouring_columns_alone_and_refuses_what_it_cannot_address():
+    """(a) `out[0]` as a [:, :, :F] slice of a WIDER tensor (observations next to other columns in one rollout
+    buffer): the kernel writes the 4k+6 floats of a row and nothing behind them — at a line-aligned pitch too (only the buffer
+    BatteryDispatchVectorEnv allocates itself is zero-padded to whole lines, negative pitch in the ABI); (b) a bid ring or
+    trajectory that 32-bit buffer offsets cannot address is an error, not silently wrong rows."""
+    import ctypes as C
+    import torch
+    from sustaingym_amd.battery import BatteryDispatchVectorEnv, synthetic_market_traces
+    N, k, R, T = 500, 36, 3, 40
+    tr = synthetic_market_traces(16, k, seed=5)
+    envs = []
+    for _ in range(3):
+        env = BatteryDispatchVectorEnv(N, k, bank_slots=16, output='torch')
+        env.upload_traces(tr)
+        env.reset(np.arange(N) % 16)
+        envs.append(env)
+    F = envs[0].F
+    g = torch.Generator(device='cuda'); g.manual_seed(2)
+    ring = (torch.rand((R, N, 2 * k), device='cuda', generator=g) * 90).contiguous()
+    ref = envs[0].rollout(ring, T, trajectory=True)[3]                       # the env's own (padded, whole-line) buffer
+    for width, env in ((192, envs[1]), (F + 10, envs[2])):                   # line-aligned pitch / an odd-looking one
+        wide = torch.full((T, N, width), -7.0, dtype=torch.float32, device='cuda')
+        rew = torch.zeros((T, N), dtype=torch.float64, device='cuda')
+        got = env.rollout(ring, T, trajectory=True, out=(wide[:, :, :F], rew))[3]
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), width
+        assert bool((wide[:, :, F:] == -7.0).all()), f'columns behind the row were written at pitch {width}'
+    # (b) sizes beyond 4 GiB: refused before anything is launched (the pointers are never dereferenced)
+    env = envs[0]
+    obs, rew1, term = env._device_buffers()
+    big_ring = (0xffffff00 // (N * 2 * k * 4)) + 1
+    rc = env.lib.bat_rollout_pitched(env.handle, C.c_void_p(ring.data_ptr()), big_ring, 4, C.c_void_p(obs.data_ptr()),
+                                     C.c_void_p(rew1.data_ptr()), C.c_void_p(term.data_ptr()), None, F, None)
+    assert rc != 0 and b'4 GiB' in env.lib.bat_last_error()
+    big_steps = (0xffffff00 // (N * 8)) + 1
+    rc = env.lib.bat_rollout_pitched(env.handle, C.c_void_p(ring.data_ptr()), R, big_steps, C.c_void_p(obs.data_ptr()),
+                                     C.c_void_p(rew1.data_ptr()), C.c_void_p(term.data_ptr()), None, F, C.c_void_p(rew1.data_ptr()))
+    assert rc != 0 and b'4 GiB' in env.lib.bat_last_error()
+    for e in envs:
+        e.close()

@@ -387,6 +387,66 @@ def test_vector_env_pipeline2_closed_loop_equals_the_default_form():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('site,project', [('caltech', True), ('jpl', True), ('caltech', False)])
+def test_vector_env_step_policy_greedy_equals_the_callers_greedy(site, project):
+    """EVChargingVectorEnv.step(policy='greedy') — the device-resident GreedyAlgorithm (baselines.py:22-35) applied inside the
+    lean streaming kernels, no action tensor — against step(sign(obs['demands'])) of a twin environment: observations, rewards,
+    terminal observations and the event state bit for bit over an episode boundary, as one launch per step and (at a size the
+    engine splits) as pipelined halves; the numpy path (host buffers) too."""
+    import torch
+    from sustaingym_amd.event_generation import DeviceGMMTraceGenerator
+    for N, pipeline, steps in ((4096, 1, 300), (32768, 2, 300)):
+        envs = [EVChargingVectorEnv(DeviceGMMTraceGenerator(site, 'Summer 2019', seed=9), num_envs=N, output='torch',
+                                    pipeline=pipeline, project_action_in_env=project) for _ in range(2)]
+        obs = [e.reset(seed=9)[0] for e in envs]
+        n = envs[0].num_stations
+        act = torch.zeros((N, n), dtype=torch.float32, device='cuda')
+        for t in range(steps):
+            envs[1].join()
+            torch.sign(obs[1]['demands'], out=act)
+            o, r, term, _, info = envs[0].step(policy='greedy')
+            o2, r2, term2, _, info2 = envs[1].step(act)
+            obs = [o, o2]
+            if t in (0, 1, 100, 150, 286, 287, 288, 299):
+                for e in envs:
+                    e.join()
+                torch.cuda.synchronize()
+                assert torch.equal(r, r2) and torch.equal(term, term2), (N, t)
+                for key in o:
+                    assert torch.equal(o[key], o2[key]), (N, key, t)
+                if t == 287:
+                    for key in o:
+                        assert torch.equal(info['final_observation'][key], info2['final_observation'][key]), key
+        for e in envs:
+            e.join()
+        torch.cuda.synchronize()
+        sa, sb = envs[0]._engine.get_state(), envs[1]._engine.get_state()
+        for key in ('scalars', 'remaining_kwh', 'departure', 'est_departure', 'breakdown', 'entry_rank'):
+            if key == 'scalars':                              # status word: the caller's float actions are never clamped either
+                assert np.array_equal(sa[key], sb[key]), key
+            else:
+                assert np.array_equal(sa[key], sb[key]), key
+        if pipeline == 2 and project:                         # (without the projection the rule runs in the debug kernels: one launch)
+            assert envs[0]._engine.pipelined_steps() >= 290   # the policy form is split into halves like the float32 form
+        for e in envs:
+            e.close()
+    # numpy path: evc_step_host with the policy kind
+    envs = [EVChargingVectorEnv(DeviceGMMTraceGenerator(site, 'Summer 2019', seed=3), num_envs=256, project_action_in_env=project)
+            for _ in range(2)]
+    obs = [e.reset(seed=3)[0] for e in envs]
+    for t in range(120):
+        a = np.sign(obs[1]['demands']).astype(np.float32)
+        o, r, term, _, _ = envs[0].step(policy='greedy')
+        o2, r2, term2, _, _ = envs[1].step(a)
+        obs = [o, o2]
+        assert np.array_equal(r, r2) and np.array_equal(term, term2), t
+        for key in o:
+            assert np.array_equal(o[key], o2[key]), (key, t)
+    for e in envs:
+        e.close()
+
+
+@pytest.mark.gpu
 def test_vector_env_batched_generator_matches_oracle_over_a_boundary():
     """EVChargingVectorEnv fed by one BatchedGMMTraceGenerator: episodes drawn in bulk (the refill
     on a worker thread), two full episodes stepped; every environment is replayed by the oracle

@@ -31,7 +31,7 @@ def test_items_come_from_the_batch_arrays():
         pass
 
 
-def test_copy_is_a_real_dict_and_extra_keys_stay():
+def test_copy_is_a_real_dict_and_extra_keys_live_for_one_step():
     s = _source()
     info = _LazyInfo(s, 1)
     c = info.copy()
@@ -40,6 +40,65 @@ def test_copy_is_a_real_dict_and_extra_keys_stay():
     assert 'episode' not in info
     info['custom'] = 7
     assert info['custom'] == 7 and 'custom' in info and 'custom' in info.keys() and len(info) == 5
-    # the object describes the CURRENT step: the source moves on, the object follows; the copy does not
+    # the object describes the CURRENT step: the source moves on, the object follows; the copy does not; what was written into
+    # the object belonged to the step it was written in
+    s.next_step()
     s.max_profit = np.array([9.0, 8.0, 7.0]); s.done = None; s.final = None
     assert info['max_profit'] == 8.0 and 'terminal_observation' not in info and c['max_profit'] == 2.5
+    assert 'custom' not in info and info.get('custom') is None and len(info) == 3 and not s.written
+
+
+def _vec_normalize_step_wait(infos, dones, scale):
+    """What stable_baselines3.common.vec_env.VecNormalize.step_wait does to the infos (v2.x, vec_normalize.py): the terminal
+    observation of the environments that ended is normalised and written back IN PLACE."""
+    for idx, done in enumerate(dones):
+        if not done:
+            continue
+        if 'terminal_observation' in infos[idx]:
+            infos[idx]['terminal_observation'] = {k: v * scale for k, v in infos[idx]['terminal_observation'].items()}
+    return infos
+
+
+def _vec_monitor_step_wait(infos, dones):
+    """VecMonitor.step_wait: copy-and-annotate (vec_monitor.py) — `info = infos[i].copy(); info['episode'] = ...`."""
+    new_infos = list(infos[:])
+    for i, done in enumerate(dones):
+        if done:
+            info = infos[i].copy()
+            info['episode'] = {'r': 1.0, 'l': 288, 't': 0.0}
+            new_infos[i] = info
+    return new_infos
+
+
+def test_in_place_wrapper_writes_do_not_outlive_their_step():
+    """VERDICT / ADVICE r5: VecNormalize's in-place overwrite of `terminal_observation` used to stay in the per-environment
+    object for good — `'terminal_observation' in info` True on every later step, and at the NEXT episode end the FIRST
+    episode's stale, already normalised observation handed out again.  Replayed over two episode boundaries with the
+    wrappers' own access patterns."""
+    s = _StepInfoSource()
+    infos = [_LazyInfo(s, i) for i in range(3)]
+
+    def step(done, final_value):
+        s.next_step()                                       # what SB3VecEnv.step_wait does first
+        s.max_profit = np.array([1.0, 2.0, 3.0])
+        s.breakdown = np.zeros((3, 3))
+        s.done = np.array(done) if any(done) else None
+        s.final = {'demands': np.full((3, 2), final_value, np.float32)} if any(done) else None
+        out = _vec_normalize_step_wait(infos, done, 0.5)
+        return _vec_monitor_step_wait(out, done)
+
+    out = step([False, True, False], 10.0)                  # first episode end of environment 1
+    assert np.array_equal(out[1]['terminal_observation']['demands'], [5.0, 5.0]) and out[1]['episode']['l'] == 288
+    assert np.array_equal(infos[1]['terminal_observation']['demands'], [5.0, 5.0])      # normalised, for THIS step
+    out = step([False, False, False], 0.0)                  # a running step: nothing terminal anywhere
+    assert all('terminal_observation' not in i for i in infos) and all('terminal_observation' not in o for o in out)
+    assert all(i.get('terminal_observation') is None for i in infos) and len(infos[1]) == 3
+    out = step([False, True, True], 30.0)                   # second boundary: this episode's observation, normalised once
+    assert np.array_equal(out[1]['terminal_observation']['demands'], [15.0, 15.0])
+    assert np.array_equal(out[2]['terminal_observation']['demands'], [15.0, 15.0])
+    assert 'terminal_observation' not in infos[0] and type(out[1]) is dict and isinstance(out[0], _LazyInfo)
+    # setdefault / update go through the same bookkeeping
+    infos[0].setdefault('x', 1); infos[0].update(y=2)
+    assert infos[0]['x'] == 1 and infos[0]['y'] == 2 and infos[0].setdefault('max_profit', -1.0) == 1.0
+    step([False, False, False], 0.0)
+    assert 'x' not in infos[0] and 'y' not in infos[0]

@@ -1,5 +1,5 @@
-"""With gymnasium / pettingzoo / stable_baselines3 importable the public classes derive from the reference's bases
-(env.py:20, wrappers.py:13, multiagent_env.py:18; SB3VecEnv: stable_baselines3's VecEnv) and the env id of sustaingym/__init__.py:3-7 is
+"""With gymnasium / pettingzoo / stable_baselines3 / ray importable the public classes derive from the reference's bases
+(env.py:20, wrappers.py:13, multiagent_env.py:18; SB3VecEnv: stable_baselines3's VecEnv; RLlibVectorEnv: ray.rllib's VectorEnv) and the env id of sustaingym/__init__.py:3-7 is
 registered.  Neither package exists in the build image, so the check runs in a subprocess against
 structural stand-ins of the two packages (just the class skeletons gymnasium 0.28 defines)."""
 import os
@@ -84,6 +84,15 @@ class DummyVenv:
 v = envs.SB3VecEnv(DummyVenv())
 assert v.num_envs == 3 and v.observation_space == 'single-obs' and v.action_space == 'single-act'
 assert v.render_mode is None and v.base_init_ran
+
+from ray.rllib.env.vector_env import VectorEnv as RayVectorEnv
+assert issubclass(envs.RLlibVectorEnv, RayVectorEnv)
+class DummyVenv2(DummyVenv):
+    single_observation_space = envs.make_observation_space(4, 2, 100.0)
+    discrete_bins = -1
+r = envs.RLlibVectorEnv(DummyVenv2())
+assert r.ray_init == (r.observation_space, 'single-act', 3) and r.observation_space.shape == (12,)
+assert len(r.get_sub_environments()) == 3
 print('OK')
 '''
 
@@ -114,6 +123,16 @@ def test_reference_bases_when_packages_exist(tmp_path):
                 assert len(modes) == num_envs
                 self.render_mode = modes[0]
                 self.base_init_ran = True
+    '''))
+    rv = tmp_path / 'ray' / 'rllib' / 'env'
+    rv.mkdir(parents=True)
+    for d in (tmp_path / 'ray', tmp_path / 'ray' / 'rllib', rv):
+        (d / '__init__.py').write_text('')
+    (rv / 'vector_env.py').write_text(textwrap.dedent('''
+        class VectorEnv:                     # ray.rllib.env.vector_env.VectorEnv.__init__ (Ray 2.x)
+            def __init__(self, observation_space, action_space, num_envs):
+                self.observation_space, self.action_space, self.num_envs = observation_space, action_space, num_envs
+                self.ray_init = (observation_space, action_space, num_envs)
     '''))
     p = tmp_path / 'pettingzoo'
     p.mkdir()
