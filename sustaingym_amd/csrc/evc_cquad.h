@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             for (int j = 0; j < kSlots; j++) {
                 const float a = a_in[j];
                 a_st[j] = fminf(fmaxf(a, 0.0f), 1.0f);                    // NaN -> 0
-                clamped = clamped || (st_valid[j] && a_st[j] != a);       // also true for NaN
+                clamped = clamped | (st_valid[j] & (a_st[j] != a));       // also true for NaN (no short circuit: three exec-mask regions)
             }
             reinterpret_cast<float4*>(act_row)[q] = make_float4(a_st[0], a_st[1], a_st[2], a_st[3]);
         }
@@ -329,11 +329,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             const unsigned mrow0 = live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) : 0u;
             moer_now0 = buf_ld_f64(r_hist, live ? mrow0 * 8u : kOob);
             mo0 = buf_ld_v4(r_mtail, (live && q < t_chunks) ? (mrow0 * (unsigned)P.mtail_w + st4) * 4u : kOob);   // chunk q of [forecast | prev | ts]
-            const bool pend0 = live && next_arrival <= t1 && cursor < n_sessions;
+            const bool pend0 = live & (next_arrival <= t1) & (cursor < n_sessions);
             const unsigned sidx0 = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
             sv0 = buf_ld_v2(r_sess, pend0 ? sidx0 * 8u : kOob);
             rq0 = buf_ld_f64(r_req, pend0 ? sidx0 * 8u : kOob);
-            nx0 = buf_ld_u32(r_sess, (pend0 && cursor + 1 < n_sessions) ? (sidx0 + 1u) * 8u : kOob);
+            nx0 = buf_ld_u32(r_sess, (pend0 & (cursor + 1 < n_sessions)) ? (sidx0 + 1u) * 8u : kOob);
         }
 #ifdef EVC_PREFETCH_EARLY          /* measurement builds: the next quad's rows requested at the top of the iteration */
         quad_next = take_quad();
@@ -392,13 +392,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         bool pilots_screened = false;
         if (PROJECT) {
             row_allreduce_words<WORDS>(ywords);
-            bool maybe = false, maybe_p = false;
-            if (q < m) {
-                const float mag2 = quad_mag2_f32<WORDS>(net, q, ywords);
-                maybe = !(mag2 < net.thr_y2[q]);
-                maybe_p = !(mag2 < net.thr_yp2[q]);
-            }
-            bool undecided = live && row_any(maybe, row);
+            // every lane evaluates "its" row (q < 16 <= EVC_MAX_CONSTRAINTS: the reads stay inside the tables; lanes q >= m read
+            // what the prologue left there and are masked) — no exec-mask region around ten LDS reads
+            const float mag2 = quad_mag2_f32<WORDS>(net, q, ywords);
+            const bool maybe = (q < m) & !(mag2 < net.thr_y2[q]);
+            const bool maybe_p = (q < m) & !(mag2 < net.thr_yp2[q]);
+            bool undecided = live & row_any(maybe, row);
             pilots_screened = !row_any(maybe_p, row);
 #ifdef EVC_COUNT_UNDECIDED         /* diagnostic builds only: environments the screen leaves undecided, in metrics[7] */
             if (undecided && q == 0u) atomicAdd(P.tie_counters + 2 * (env & (kTieSlots - 1)) + 1, 1ull);
