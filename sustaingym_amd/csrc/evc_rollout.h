@@ -309,6 +309,9 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
     };
     v4u act_next = fetch_actions(0);
 
+#ifdef EVC_ROLLOUT_STATS      /* measurement builds (tools/rollout_stats.py): per wavefront into Params::slow_list — 100 MHz ticks of the whole loop, inside the rare projection branch, inside the solve call; visits and calls */
+    unsigned ms_t0 = (unsigned)__builtin_amdgcn_s_memrealtime(), ms_rare = 0u, ms_call = 0u, ms_calls = 0u, ms_visits = 0u;
+#endif
     for (int step = 0; step < io.steps; step++) {
         const bool after_done = ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
         const bool live = ev && !after_done;
@@ -411,6 +414,10 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
 #else
             if (__builtin_expect(__ballot(undecided) != 0ull, 0)) {
 #endif
+#ifdef EVC_ROLLOUT_STATS
+                const unsigned ms_r0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+                ms_visits += 1u;
+#endif
                 int st_gid[kSlots];
 #pragma unroll
                 for (int c = 0; c < kSlots; c++) st_gid[c] = valid[c] ? (int)(st_info[st[c]] & 0x7fu) : -1;
@@ -493,7 +500,13 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                                           ((solve_mask & 0xffff00000000ull) ? 4u : 0u) | ((solve_mask >> 48) ? 8u : 0u) |
                                           (KIND != 0 ? 16u : 0u) | (KIND == 0 ? (unsigned)(step + 1) << 8 : 0u);
                     lds_sync();
+#ifdef EVC_ROLLOUT_STATS
+                    const unsigned ms_c0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
                     rollout_solve_rows((unsigned)(size_t)(__attribute__((address_space(3))) void*)&S, wv, rows);
+#ifdef EVC_ROLLOUT_STATS
+                    ms_call += (unsigned)__builtin_amdgcn_s_memrealtime() - ms_c0; ms_calls += 1u;
+#endif
                     lds_sync();
 #pragma unroll
                     for (int c = 0; c < NS; c++)
@@ -507,6 +520,9 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                     lds_sync();
                 }
                 pilots_screened = pilots_screened && !undecided;
+#ifdef EVC_ROLLOUT_STATS
+                ms_rare += (unsigned)__builtin_amdgcn_s_memrealtime() - ms_r0;
+#endif
             }
         }
 
@@ -673,6 +689,12 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
         }
     }
 
+#ifdef EVC_ROLLOUT_STATS
+    if (lane == 0u && quad < 16384u) {
+        unsigned* o = (unsigned*)P.slow_list + quad * 4u;
+        o[0] = (unsigned)__builtin_amdgcn_s_memrealtime() - ms_t0; o[1] = ms_rare; o[2] = ms_call; o[3] = ms_calls | (ms_visits << 16);
+    }
+#endif
     // ---- registers -> memory: compact state, then the outputs of the last step ----
     {
         unsigned count = 0u;
