@@ -1131,7 +1131,7 @@ def secondary_battery_rollout(dev_index, N=16384, T=EPISODE) -> dict:
     rew_traj = torch.empty((T, N), dtype=torch.float64, device=dev)
     # the trajectory as BatteryDispatchVectorEnv.rollout allocates it by default — rows 160 floats (640 B) apart, the
     # [T, N, 150] view handed out (bat_rollout_pitched, round 5) — and with packed 600-byte rows (round 4's form)
-    bufs = {'with_trajectory': (torch.zeros((T, N, 160), dtype=torch.float32, device=dev)[:, :, :F], rew_traj),
+    bufs = {'with_trajectory': env.new_trajectory(T),          # rows 640 B apart, padding owned by the kernel: whole-line stores
             'with_trajectory_packed_rows': (torch.empty((T, N, F), dtype=torch.float32, device=dev), rew_traj),
             'last_outputs_only': None}
     slots = np.arange(N) % 1024

@@ -69,6 +69,7 @@ class BatteryDispatchVectorEnv:
         self._rew = np.zeros(self.N, np.float64)
         self._term = np.zeros(self.N, np.uint8)
         self._dev = None
+        self._owned_traj: dict = {}       # data_ptr of a trajectory view made by new_trajectory() -> its padded allocation
 
     def _check(self, rc, what):
         if rc != 0:
@@ -119,6 +120,19 @@ class BatteryDispatchVectorEnv:
                                            self._term.ctypes.data), 'bat_step_host')
         return self._obs.copy(), self._rew.copy(), self._term.astype(bool)
 
+    def new_trajectory(self, steps: int):
+        """``(obs_traj [steps, N, 4k+6] float32, reward_traj [steps, N] float64)`` for ``rollout(..., out=...)``, allocated the way
+        ``rollout`` does it itself: observation rows 640 B apart (a whole number of 128-byte lines), zero-filled, the ``[:, :, :4k+6]``
+        view handed out.  The padding behind each row belongs to the kernel (whole-line non-temporal stores): buffers made here
+        are remembered, any OTHER strided view passed as ``out`` only ever has its 4k+6 floats per row written."""
+        import torch
+        obs, _, _ = self._device_buffers()
+        pitch = (self.F + 31) // 32 * 32
+        store = torch.zeros((steps, self.N, pitch), dtype=torch.float32, device=obs.device)
+        view = store[:, :, :self.F]
+        self._owned_traj[view.data_ptr()] = store            # (keeps the allocation alive as long as the environment)
+        return view, torch.zeros((steps, self.N), dtype=torch.float64, device=obs.device)
+
     def rollout(self, bids_ring, steps: int, trajectory: bool = False, out=None):
         """``steps`` steps in ONE launch (``bat_rollout``): step i uses ``bids_ring[i % R]`` (CUDA float32 ``[R, N, 2k]``).
         Returns ``(obs, reward, terminated)`` of the last step (the persistent buffers of ``step``) and, with
@@ -134,15 +148,16 @@ class BatteryDispatchVectorEnv:
             if out is None:
                 # rows 640 B apart (a multiple of the 128-byte line; bat_rollout_pitched): the [steps, N, 4k+6] VIEW is handed out.
                 # Zero-filled: the rows of steps after an environment's termination are not written by the kernel.
-                pitch = (self.F + 31) // 32 * 32
-                store = torch.zeros((steps, self.N, pitch), dtype=torch.float32, device=obs.device)
-                traj = (store[:, :, :self.F], torch.zeros((steps, self.N), dtype=torch.float64, device=obs.device))
-                pitch = -pitch           # the padding of OUR allocation is the kernel's to fill: whole-line stores (battery_dispatch.h)
+                traj = self.new_trajectory(steps)
+                del self._owned_traj[traj[0].data_ptr()]      # handed out for good: nothing to remember
+                pitch = -int(traj[0].stride(1))   # the padding of OUR allocation is the kernel's to fill: whole-line stores (battery_dispatch.h)
             else:
                 traj = out
                 assert tuple(traj[0].shape) == (steps, self.N, self.F) and tuple(traj[1].shape) == (steps, self.N)
                 assert traj[0].stride(2) == 1 and traj[0].stride(0) == self.N * traj[0].stride(1), 'obs_traj: rows at a constant pitch'
                 pitch = int(traj[0].stride(1))   # positive: nothing behind the 4k+6 floats of a row is written (a caller's wider tensor)
+                if traj[0].data_ptr() in self._owned_traj and traj[0].shape[0] <= self._owned_traj[traj[0].data_ptr()].shape[0]:
+                    pitch = -pitch               # a buffer new_trajectory() made: its padding is the kernel's
         self._check(self.lib.bat_rollout_pitched(self.handle, C.c_void_p(bids_ring.data_ptr()), int(bids_ring.shape[0]), int(steps),
                                                  C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(term.data_ptr()),
                                                  C.c_void_p(traj[0].data_ptr()) if traj else None, pitch,

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     // odd); tail [forecasted_moer k | prev_moer | timestep] = k + 2 floats = t_full whole chunks + t_rem floats
     const unsigned c_full = (2u * n) >> 2, t_full = (k + 2u) >> 2, t_rem = (k + 2u) & 3u;
     const unsigned t_chunks = (unsigned)P.mtail_w >> 2;
+    const unsigned qrow = q < m ? q : 0u;             // the constraint row this lane screens
 
     const rsrc_t r_win = row_rsrc(P.win_base, P.win_span);      // every engine-owned array (struct Win)
     const Win r_rem{r_win, P.off_rem}, r_de{r_win, P.off_de};
@@ -392,11 +393,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         bool pilots_screened = false;
         if (PROJECT) {
             row_allreduce_words<WORDS>(ywords);
-            // every lane evaluates "its" row (q < 16 <= EVC_MAX_CONSTRAINTS: the reads stay inside the tables; lanes q >= m read
-            // what the prologue left there and are masked) — no exec-mask region around ten LDS reads
-            const float mag2 = quad_mag2_f32<WORDS>(net, q, ywords);
-            const bool maybe = (q < m) & !(mag2 < net.thr_y2[q]);
-            const bool maybe_p = (q < m) & !(mag2 < net.thr_yp2[q]);
+            // Every lane evaluates a row — lanes q >= m repeat row 0, which changes no row_any() — so that the predicates handed
+            // to the ballots are plain compares (LLVM lowers __ballot of anything else through v_cndmask + v_cmp) and no exec-mask
+            // region surrounds the ten LDS reads.
+            const float mag2 = quad_mag2_f32<WORDS>(net, qrow, ywords);
+            const bool maybe = !(mag2 < net.thr_y2[qrow]);
+            const bool maybe_p = !(mag2 < net.thr_yp2[qrow]);
             bool undecided = live & row_any(maybe, row);
             pilots_screened = !row_any(maybe_p, row);
 #ifdef EVC_COUNT_UNDECIDED         /* diagnostic builds only: environments the screen leaves undecided, in metrics[7] */
@@ -485,17 +487,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         };
 #pragma unroll
         for (int c = 0; c < NS; c++) charge(c);
-        {   // the period in which an EV reaches the ramp-down line (continuous battery model): once per
-            // session at most, so the exponential sits behind a wave-uniform branch
-            bool any_cross = false;
+        // the period in which an EV reaches the ramp-down line (continuous battery model): once per session at most, so the
+        // exponential sits behind a branch — the exec-mask region of the lanes concerned, which is skipped when there is none
+        // (s_cbranch_execz; a wave-level __ballot in front of it cost two vector instructions per quad)
 #pragma unroll
-            for (int c = 0; c < NS; c++) any_cross = any_cross || cross[c];
-            if (__builtin_expect(__ballot(any_cross) != 0ull, 0)) {
-#pragma unroll
-                for (int c = 0; c < NS; c++)
-                    if (cross[c]) amps[c] = charge_ev_cross(pilot[c], rem_in[c], rem[c]);
-            }
-        }
+        for (int c = 0; c < NS; c++)
+            if (__builtin_expect(cross[c], 0)) amps[c] = charge_ev_cross(pilot[c], rem_in[c], rem[c]);
         double amps_sum = 0.0;                     // env.py:445: delivered amps, summed over the entries (order: slot, then lane)
 #pragma unroll
         for (int c = 0; c < NS; c++) amps_sum += (live && valid[c]) ? amps[c] : 0.0;
@@ -519,7 +516,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // With the projection the y-screen above usually proves the pilots feasible as well
         // (pilots_screened); their class sums are only formed for wavefronts where some row is open.
         double excess = 0.0;
-        if (station_pilots || __ballot(live && !pilots_screened) != 0ull) {
+        if (station_pilots || (live && !pilots_screened)) {          // (row-uniform: whole 16-lane rows take part in the DPP sums)
             if (!station_pilots) {
 #pragma unroll
                 for (int c = 0; c < NS; c++) {
@@ -547,7 +544,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 #pragma unroll
         for (int c = 0; c < kSlots; c++) { alive[c] = false; pos[c] = 0u; }
         auto pack = [&](int c) {
-            alive[c] = valid[c] && dep[c] > t1;
+            alive[c] = dep[c] > t1;                                      // (dep is kEmptyDep = -1 where the slot holds no entry: a plain compare)
             const unsigned bits = (unsigned)(__ballot(alive[c]) >> (row * 16u)) & 0xffffu;
             pos[c] = count + (unsigned)__popc(bits & ((1u << q) - 1u));
             count += (unsigned)__popc(bits);
@@ -569,7 +566,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         unsigned long long arrived = 0ull;                               // stations plugged in this pass
         bool pending = live && next_arrival <= t1 && cursor < n_sessions;
         bool first_pass = kEarly;                   // the first record of the period was requested at the top of the iteration
-        while (__ballot(pending) != 0ull) {
+        while (pending) {                                                // (row-uniform; rows without an arrival sit the loop out)
             const unsigned sidx = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
             v2u sv;
             double rq;
@@ -702,7 +699,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         // ---- autoreset (gymnasium VectorEnv): terminal observation, then next episode's state ----
         const bool do_reset = done && P.autoreset;
         if (done) episodes += 1;
-        if (__builtin_expect(__ballot(do_reset) != 0ull, 0)) {
+        if (__builtin_expect(do_reset, 0)) {                             // (row-uniform; per-lane work only)
             if (io.out.final_obs) {
                 const rsrc_t r_fin = row_rsrc(io.out.final_obs, N * F * 4u);
                 store_obs(r_fin, do_reset);
