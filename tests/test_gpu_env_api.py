@@ -508,6 +508,12 @@ def test_vector_env_device_generation_matches_oracle_generator_and_step():
         if t == 287:
             assert term.all() and np.allclose(info['final_info']['max_profit'], mp[:N])
             assert np.allclose(info['max_profit'], mp[N:2 * N])
+            # the max_profit values of the slots refilled at THIS boundary stay on the GPU until those episodes are
+            # played — the boundary step does not wait for the generating kernel it has just launched
+            assert venv._max_profit_pending == [(0, N)]
+        if t == 288:
+            assert venv._max_profit_pending == [(0, N)]                       # still: this episode reads slots [N, 2N)
+    assert venv._max_profit_pending == [(N, N)]                               # second boundary: [0, N) fetched, [N, 2N) refilled
     assert dg.next_episode == 4 * N
     for e in range(0, N, 7):
         for ep in range(3):                       # env e plays episodes e, N+e, 2N+e
