@@ -193,8 +193,19 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
     stage_net(net, P);                              // ends with the workgroup barrier
 
     const unsigned nquads = (N + 3u) >> 2;
-    const unsigned quad = blockIdx.x * 4u + wv;
-    if (quad >= nquads) return;                     // (after the only barrier)
+    // persistent wavefronts (round 6): the first quad by position, every further one from RolloutIO::quad_counter
+    auto next_quad = [&]() {
+        unsigned nq = 0u;
+        if (lane == 0u) nq = __hip_atomic_fetch_add(io.quad_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (unsigned)rfl((int)nq);
+    };
+    for (unsigned quad = blockIdx.x * 4u + wv; quad < nquads; quad = next_quad()) {      // (after the only barrier)
+    // what the previous quad of this wavefront left in its share of the workgroup's LDS: warm-start tags are periods of THAT quad
+    if (q == 0u) S.warm_tag[wv][row] = 0;
+    if (lane == 0u) S.noconv[wv] = 0;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
     const unsigned env = quad * 4u + row;
     const bool ev = env < N;
     const unsigned ebase = env * n;
@@ -310,7 +321,8 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
     v4u act_next = fetch_actions(0);
 
 #ifdef EVC_ROLLOUT_STATS      /* measurement builds (tools/rollout_stats.py): per wavefront into Params::slow_list — 100 MHz ticks of the whole loop, inside the rare projection branch, inside the solve call; visits and calls */
-    unsigned ms_t0 = (unsigned)__builtin_amdgcn_s_memrealtime(), ms_rare = 0u, ms_call = 0u, ms_calls = 0u, ms_visits = 0u;
+    unsigned ms_t0 = (unsigned)__builtin_amdgcn_s_memrealtime(), ms_rare = 0u, ms_call = 0u, ms_calls = 0u, ms_visits = 0u, ms_exact = 0u, ms_fill = 0u, ms_short = 0u, ms_fills = 0u, ms_fillcalls = 0u;
+    unsigned long long ms_passes = 0ull;
 #endif
     for (int step = 0; step < io.steps; step++) {
         const bool after_done = ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
@@ -452,6 +464,11 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                     const bool hard = quad_exact_rows(S.rare.G, S.rare.class_cap, net, q, m, st_gid, y, undecided, cap_viol);
                     anyviol = row_any(hard, row);
                 }
+#ifdef EVC_ROLLOUT_STATS
+                const unsigned ms_r1 = (unsigned)__builtin_amdgcn_s_memrealtime();
+                ms_exact += ms_r1 - ms_r0;
+                ms_short += shortcut ? 1u : 0u;
+#endif
 #if defined(EVC_RABL) && EVC_RABL == 2   /* ablation (WRONG results): exact rows only */
                 const bool fill = false;
                 anyviol = false;
@@ -464,7 +481,11 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                     for (int c = 0; c < kSlots; c++) slot_cc[c] = valid[c] && (st_info[st[c]] >> 7) != 0u;
                     for (int g = 0; g < S.rare.G; g++) {
                         const bool do_g = fill && ((cap_viol >> g) & 1u);
+#ifdef EVC_ROLLOUT_STATS
+                        if (__ballot(do_g) != 0ull) { ms_fillcalls += 1u; quad_waterfill(do_g, g, st_gid, act, dep, rem, S.rare.class_cap[g], y, slot_cc, nullptr, S.rare.tie_log2, &ms_passes); }
+#else
                         if (__ballot(do_g) != 0ull) quad_waterfill(do_g, g, st_gid, act, dep, rem, S.rare.class_cap[g], y, slot_cc, nullptr, S.rare.tie_log2);
+#endif
                     }
 #if defined(EVC_RABL) && EVC_RABL == 3   /* ablation (WRONG results): exact rows + filling, no second evaluation, no solve */
                     anyviol = false;
@@ -479,6 +500,10 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
                 }
 #if defined(EVC_RABL) && EVC_RABL == 4   /* ablation (WRONG results): everything but the solve */
                 anyviol = false;
+#endif
+#ifdef EVC_ROLLOUT_STATS
+                ms_fill += (unsigned)__builtin_amdgcn_s_memrealtime() - ms_r1;
+                ms_fills += __ballot(fill) != 0ull ? 1u : 0u;
 #endif
                 const bool solve_me = undecided && anyviol;       // cone rows bind (or unsettled): iterative solver
                 const unsigned long long solve_mask = __ballot(solve_me);
@@ -693,6 +718,9 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
     if (lane == 0u && quad < 16384u) {
         unsigned* o = (unsigned*)P.slow_list + quad * 4u;
         o[0] = (unsigned)__builtin_amdgcn_s_memrealtime() - ms_t0; o[1] = ms_rare; o[2] = ms_call; o[3] = ms_calls | (ms_visits << 16);
+        // (the list holds N ints = four per wavefront: the second half of the wavefronts reports the split of the visit instead)
+        // second record: exact-rows ticks, filling ticks, visits that took the caps-only shortcut, visits with a filling
+        if (quad >= 8192u && quad < 16384u) { o[0] = (unsigned)ms_passes | (ms_fillcalls << 16); o[1] = ms_exact; o[2] = ms_fill; o[3] = ms_short | (ms_fills << 16); }
     }
 #endif
     // ---- registers -> memory: compact state, then the outputs of the last step ----
@@ -728,6 +756,7 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
         buf_st_f64(r_bd, (ever_live && q < 3u) ? env * 24u + q * 8u : kOob, bd);
         if (io.out.returns && ev && q == 0u) io.out.returns[env] = ret;
     }
+    }   // next quad of this wavefront
 }
 
 }  // namespace evc

@@ -17,6 +17,11 @@ struct RolloutIO {
     unsigned env_id_base;        // global id of environment 0 (random stream)
     unsigned long long seed;     // random stream key
     evc_step_out out;
+    // Round 6: the grid is persistent (as many workgroups as stay resident) and a wavefront that has finished its quad's T
+    // periods takes the next quad from this counter (device memory; the engine sets it to 4 x grid before the launch: the first
+    // quads are assigned by position).  Wavefront times differ by 3x on congested days; with one quad per wavefront and four
+    // wavefronts per workgroup a launch took 13 mean wavefront times where 8 rounds were resident (tools/rollout_stats.py).
+    unsigned* quad_counter;
 };
 
 // Launches rollout_kernel<P.project, (P.G + 1) / 2, policy kind (0 greedy, 1 random, 2 replay)> on `stream`; with start / stop events

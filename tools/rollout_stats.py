@@ -28,7 +28,8 @@ dt = (time.perf_counter() - t0) / 3
 print(f'{site}: {dt / 288 * 1e6:.2f} us per period, build at {w.eng.last_rollout_waves()} wavefronts per SIMD')
 raw = np.zeros(65536, dtype=np.int32)
 w.eng.lib.evc_debug_read_slow_list(w.eng.handle, raw.ctypes.data_as(C.c_void_p), 65536)
-st = raw.view(np.uint32).reshape(16384, 4).astype(float)
+st_all = raw.view(np.uint32).reshape(16384, 4).astype(float)
+st = st_all[:8192]                   # wavefronts 0 .. 8191: loop / rare branch / solve call; 8192 ..: the split of the visit
 tot, rare, call = st[:, 0] * 0.01, st[:, 1] * 0.01, st[:, 2] * 0.01
 calls, visits = np.floor(st[:, 3] % 65536), np.floor(st[:, 3] / 65536)
 pc = lambda a: ' '.join(f'{x:9.1f}' for x in np.percentile(a, [1, 10, 50, 90, 99, 100]))
@@ -41,4 +42,12 @@ print('visits of the rare branch           ', pc(visits))
 print(f'per visit {rare.sum() / max(visits.sum(), 1):.2f} us (calls included), per call {call.sum() / max(calls.sum(), 1):.1f} us; loop without the branch {(tot - rare).mean() / 288:.2f} us per period')
 print(f'means: loop {tot.mean():.1f} us, rare {rare.mean():.1f}, call {call.mean():.1f} ({call.sum() / max(calls.sum(), 1):.1f} us per call); '
       f'launch / mean wavefront loop = {dt * 1e6 / tot.mean():.2f} (8 wavefront rounds of 2 per SIMD would be 8.0)')
+s2 = st_all[8192:]
+ex, fl = s2[:, 1] * 0.01, s2[:, 2] * 0.01
+short, fills = np.floor(s2[:, 3] % 65536), np.floor(s2[:, 3] / 65536)
+passes, fcalls = np.floor(s2[:, 0] % 65536), np.floor(s2[:, 0] / 65536)
+v2 = max(visits.mean(), 1e-9)
+print(f'split of a visit (second half of the wavefronts): exact rows / shortcut test {ex.mean() / v2:.2f} us, fillings + second evaluation {fl.mean() / v2:.2f} us per visit; '
+      f'{short.mean() / v2:.2f} of the visits take the caps-only shortcut, {fills.mean() / v2:.2f} have a filling; '
+      f'{fcalls.mean() / v2:.2f} class fillings per visit, {passes.mean() / max(fcalls.mean(), 1e-9):.2f} Newton passes per filling')
 w.close()
