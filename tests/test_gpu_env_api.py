@@ -447,6 +447,34 @@ def test_vector_env_step_policy_greedy_equals_the_callers_greedy(site, project):
 
 
 @pytest.mark.gpu
+def test_vector_env_step_policy_random_equals_the_staged_random_actions():
+    """EVChargingVectorEnv.step(policy='random') — RandomAlgorithm (baselines.py:38-51) on the engine's counter-based stream —
+    against a twin that fetches the very actions the policy would apply (StepEngine.fill_random_actions) and hands them in:
+    bit for bit over an episode boundary, continuous and DiscreteActionWrapper levels."""
+    import torch
+    from sustaingym_amd.event_generation import DeviceGMMTraceGenerator
+    for bins in (-1, 5):
+        envs = [EVChargingVectorEnv(DeviceGMMTraceGenerator('caltech', 'Summer 2019', seed=2), num_envs=1024, output='torch',
+                                    discrete_bins=bins) for _ in range(2)]
+        for e in envs:
+            e.reset(seed=2)
+            e._engine.set_policy_seed(99)
+        for t in range(300):
+            a = envs[1]._engine.fill_random_actions(bins=max(bins, 0))            # float32 levels in [0, 1]
+            o, r, term, _, _ = envs[0].step(policy='random')
+            if bins > 0:
+                a = torch.round(a * (bins - 1)).to(torch.int64)                   # what a caller of the wrapper passes
+            o2, r2, term2, _, _ = envs[1].step(a)
+            if t % 37 == 0 or t in (286, 287, 288):
+                torch.cuda.synchronize()
+                assert torch.equal(r, r2) and torch.equal(term, term2), (bins, t)
+                for key in o:
+                    assert torch.equal(o[key], o2[key]), (bins, key, t)
+        for e in envs:
+            e.close()
+
+
+@pytest.mark.gpu
 def test_vector_env_batched_generator_matches_oracle_over_a_boundary():
     """EVChargingVectorEnv fed by one BatchedGMMTraceGenerator: episodes drawn in bulk (the refill
     on a worker thread), two full episodes stepped; every environment is replayed by the oracle
