@@ -80,6 +80,7 @@ struct evc_engine {
     int* d_slot_moer = nullptr;
     double* d_moer_hist = nullptr;
     float* d_moer_obs = nullptr;
+    unsigned* d_roll_order = nullptr;     // quads of a fused rollout launch, busiest first (RolloutIO::quad_order)
     unsigned* d_roll_ctr = nullptr;       // next unassigned quad of a fused rollout launch (RolloutIO::quad_counter)
     CqBlob* d_cq_blob = nullptr;         // prologue image of the compact streaming kernel (Params::cq_blob)
     float* d_moer_tail = nullptr;        // [moer_days][289][mtail_w]: the observation row's tail, ready to store (Params::off_mtail)
@@ -194,7 +195,7 @@ void free_all(evc_engine* e) {
                     e->d_nsess, e->d_slot_moer,
                     e->d_slow_count, e->d_slow_list, e->d_idbuf, e->d_metrics, e->d_act, e->d_act_f32, e->d_obs,
                     e->d_reward, e->d_term, e->d_breakdown, e->d_final, e->d_pilots, e->d_rates,
-                    e->d_proj, e->d_maxprofit, e->d_gen, e->d_tie, e->d_cq_blob, e->d_roll_ctr};
+                    e->d_proj, e->d_maxprofit, e->d_gen, e->d_tie, e->d_cq_blob, e->d_roll_ctr, e->d_roll_order};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ev : e->ev)
@@ -800,6 +801,14 @@ int launch_rollout(evc_engine* e, const void* actions_dev, int ring_len, int act
     }
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)e->d_roll_ctr, (int)(4 * pgrid), 1, e->stream));
     io.quad_counter = e->d_roll_ctr;
+    io.quad_order = nullptr;
+    {   // busiest quads first (one small launch in front; EVC_ROLLOUT_ORDER=0: by index — measurements)
+        static const bool ordered = !(getenv("EVC_ROLLOUT_ORDER") && atoi(getenv("EVC_ROLLOUT_ORDER")) == 0);
+        if (ordered && grid > pgrid) {                 // (with every quad resident from the start there is nothing to order)
+            launch_rollout_order(e->P, e->d_roll_order, e->stream);
+            io.quad_order = e->d_roll_order;
+        }
+    }
     if (!launch_rollout_kernel(e->P, io, pgrid, e->stream, ev0, ev1, waves))
         return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
     e->last_rollout_waves = waves;
@@ -928,6 +937,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
     A(dmalloc(&e->d_metrics, 8));
     A(hipMalloc((void**)&e->d_cq_blob, sizeof(CqBlob)));
     A(hipMalloc((void**)&e->d_roll_ctr, 64));
+    A(hipMalloc((void**)&e->d_roll_order, sizeof(unsigned) * ((N + 3) / 4)));
     if (err != hipSuccess) {
         free_all(e);
         delete e;

@@ -194,12 +194,18 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
 
     const unsigned nquads = (N + 3u) >> 2;
     // persistent wavefronts (round 6): the first quad by position, every further one from RolloutIO::quad_counter
+    // (positions in RolloutIO::quad_order, busiest quads first, when the engine supplies it)
+    auto quad_at = [&](unsigned pos) {
+        unsigned qd = pos;
+        if (io.quad_order != nullptr && pos < nquads) qd = (unsigned)rfl((int)io.quad_order[pos]);
+        return pos < nquads ? qd : nquads;
+    };
     auto next_quad = [&]() {
         unsigned nq = 0u;
         if (lane == 0u) nq = __hip_atomic_fetch_add(io.quad_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (unsigned)rfl((int)nq);
+        return quad_at((unsigned)rfl((int)nq));
     };
-    for (unsigned quad = blockIdx.x * 4u + wv; quad < nquads; quad = next_quad()) {      // (after the only barrier)
+    for (unsigned quad = quad_at(blockIdx.x * 4u + wv); quad < nquads; quad = next_quad()) {      // (after the only barrier)
     // what the previous quad of this wavefront left in its share of the workgroup's LDS: warm-start tags are periods of THAT quad
     if (q == 0u) S.warm_tag[wv][row] = 0;
     if (lane == 0u) S.noconv[wv] = 0;

@@ -7,6 +7,38 @@
 
 namespace evc {
 
+constexpr int kOrderBins = 1024;
+__global__ __launch_bounds__(1024) void rollout_order_kernel(Params P, unsigned* __restrict__ order) {
+    __shared__ unsigned hist[kOrderBins];
+    const unsigned tid = threadIdx.x, N = (unsigned)P.N, nquads = (N + 3u) >> 2;
+    hist[tid] = 0u;
+    __syncthreads();
+    auto key_of = [&](unsigned quad) {
+        unsigned key = 0u;
+        for (unsigned r = 0; r < 4u; r++) {
+            const unsigned env = quad * 4u + r;
+            if (env < N) {
+                const int4 s0 = P.scal[2 * env], s1 = P.scal[2 * env + 1];
+                const int left = s0.x >= EVC_EPISODE_STEPS ? 0 : (s1.x - s0.y);          // sessions behind the cursor (none once the episode is over)
+                key += (unsigned)(left > 0 ? left : 0) + (((unsigned)s1.z >> kCountShift) & 0x7fu);
+            }
+        }
+        return key < (unsigned)kOrderBins ? key : (unsigned)kOrderBins - 1u;
+    };
+    for (unsigned quad = tid; quad < nquads; quad += 1024u) atomicAdd(&hist[key_of(quad)], 1u);
+    __syncthreads();
+    if (tid == 0u) {                                   // exclusive prefix, busiest bin first (1 024 bins: a serial pass is a microsecond)
+        unsigned at = 0u;
+        for (int b = kOrderBins - 1; b >= 0; b--) { const unsigned c = hist[b]; hist[b] = at; at += c; }
+    }
+    __syncthreads();
+    for (unsigned quad = tid; quad < nquads; quad += 1024u) order[atomicAdd(&hist[key_of(quad)], 1u)] = quad;
+}
+
+void launch_rollout_order(const Params& P, unsigned* order, hipStream_t stream) {
+    hipLaunchKernelGGL(rollout_order_kernel, dim3(1), dim3(1024), 0, stream, P, order);
+}
+
 bool launch_rollout_kernel(const Params& P, const RolloutIO& io, int grid, hipStream_t stream, hipEvent_t start, hipEvent_t stop,
                            int waves) {
     const int words = (P.G + 1) / 2;

@@ -22,7 +22,15 @@ struct RolloutIO {
     // quads are assigned by position).  Wavefront times differ by 3x on congested days; with one quad per wavefront and four
     // wavefronts per workgroup a launch took 13 mean wavefront times where 8 rounds were resident (tools/rollout_stats.py).
     unsigned* quad_counter;
+    // ... in the order of this list (nquads entries; NULL: by index): the engine sorts the quads by the sessions their
+    // environments still have to serve (rollout_order_kernel), busiest first, so that the launch does not end on a long quad
+    // that happened to be dispatched last.
+    const unsigned* quad_order;
 };
+
+// One launch of one workgroup: order[0 .. nquads) = the quads sorted by descending load estimate (counting sort; key = sessions
+// not yet arrived + EVs plugged in, summed over the quad's four environments, from the per-environment scalars).
+void launch_rollout_order(const Params& P, unsigned* order, hipStream_t stream);
 
 // Launches rollout_kernel<P.project, (P.G + 1) / 2, policy kind (0 greedy, 1 random, 2 replay)> on `stream`; with start / stop events
 // the launch carries them (hipExtLaunchKernel: the dispatch's own begin / end timestamps).  waves = 2 | 3: the register
