@@ -1105,6 +1105,8 @@ def secondary_battery(dev_index, N=16384) -> dict:
     alg = (4 * k + 6) * 4 + 2 * k * 4 + 8 + 1 + 2 * 16          # obs row + bids + reward + done + state r/w
     env.close()
     return {'workload': f'{N} battery-dispatch envs (synthetic price-taker step), k={k}',
+            'parity': 'synthetic specification (no ElectricityMarketEnv code in the reference): oracle parity at N = 37 / 1 000 / 4 096 '
+                      '(tests/test_gpu_battery.py), property checks only at this size',
             'ms_per_step': round(wall, 5), 'env_steps_per_s': round(N / wall * 1e3, 1), 'gpu_ms_per_step': round(gpu, 5),
             'roofline': {'bound': 'hbm', 'kernel': 'bat::step_kernel', 'algorithmic_bytes_per_env_step': alg,
                          'achieved': round(alg * N / (gpu * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
