@@ -181,6 +181,10 @@ def parse_args(argv=None):
                         'logic with several ranks on ONE GPU, see --single-device)')
     p.add_argument('--single-device', action='store_true',
                    help='testing aid: every rank uses cuda:0 (needs --backend gloo)')
+    p.add_argument('--settle-steps', type=int, default=EPISODE,
+                   help='untimed steps at the end of the set-up, in front of the --warmup steps: SURVEY 8(d) defines the metric in steady '
+                        'state "excluding one warm-up episode", and with a short --warmup (the driver: 5) the timed window would otherwise '
+                        "begin on a GPU that has idled through the set-up's host work (clocks down).  Default: one episode")
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-secondary', action='store_true', help='skip the secondary records (GMM days, multi-agent, battery)')
     p.add_argument('--leg-budget-s', type=float, default=60.0, help='time box of one secondary record')
@@ -1257,6 +1261,7 @@ def main():
     # counters are read BEFORE the warm-up steps: nothing but the barrier stands between the warm-up and the timed steps
     # (a metrics kernel + copy there leaves the GPU idle for a few hundred microseconds more)
     # (same-box A/B, 10 interleaved runs of the 20-step window: 26.0 against 27.2 us per step pipelined, no difference with one launch per step)
+    w.run(args.settle_steps)                     # set-up: one untimed episode (steady state, clocks up); not part of --warmup / --steps
     steps0 = w.eng.read_metrics()['env_steps'] + float(N) * args.warmup
     w.run(args.warmup)
     barrier()
@@ -1385,7 +1390,7 @@ def main():
                        'phase': args.phase,
                        'pipeline': ('2 half-batch launches per step on 2 streams (evc_set_pipeline): all outputs of every step written, '
                                     'the halves\' launches overlap across steps' if w.pipeline == 2 else '1 launch per step'),
-                       'launches_per_step': 2 if w.pipeline == 2 else 1,
+                       'launches_per_step': 2 if w.pipeline == 2 else 1, 'settle_steps': args.settle_steps,
                        'pipelined_steps_timed': int(pipelined_timed)},
             # proof that `world` ranks stepped: gathered over the process group
             'ranks_seen': int(per_rank.shape[0]),
