@@ -614,7 +614,7 @@ def secondary_rollout(policy, dev_index, battery, episodes='synthetic', site='ca
     # its bound is VALU issue.  Instructions per env-step come from the SQ counters of tools/profile_rollout.sh
     # (profiles/r3_rollout_*.json); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md).
     valu = valu_src = None
-    for rnd in ('r5', 'r3'):                              # the newest committed SQ-counter record of this workload
+    for rnd in ('r6', 'r5', 'r3'):                        # the newest committed SQ-counter record of this workload
         try:
             valu_src = f'profiles/{rnd}_rollout_{site}_{"synthetic" if episodes == "synthetic" else "gmm"}_{policy}.json'
             valu = json.load(open(os.path.join(ROOT, valu_src)))['SQ_INSTS_VALU']
