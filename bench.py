@@ -185,6 +185,8 @@ def parse_args(argv=None):
                    help='untimed steps at the end of the set-up, in front of the --warmup steps: SURVEY 8(d) defines the metric in steady '
                         'state "excluding one warm-up episode", and with a short --warmup (the driver: 5) the timed window would otherwise '
                         "begin on a GPU that has idled through the set-up's host work (clocks down).  Default: one episode")
+    p.add_argument('--host-wait', default='spin', choices=['spin', 'auto'],
+                   help="how the rank's host thread waits in torch.cuda.synchronize(): 'spin' (default: hipDeviceScheduleSpin) or the runtime's choice")
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-secondary', action='store_true', help='skip the secondary records (GMM days, multi-agent, battery)')
     p.add_argument('--leg-budget-s', type=float, default=60.0, help='time box of one secondary record')
@@ -1222,6 +1224,18 @@ def main():
     if must_spawn:
         sys.exit(spawn_ranks(args.gpus))
 
+    host_wait = 'auto'
+    if args.host_wait == 'spin' and os.environ.get('BENCH_SPIN_WAIT', '1') != '0':
+        # The host thread of a rank has nothing to do but wait at the barriers: let its synchronisations SPIN instead of yielding
+        # (hipDeviceScheduleSpin; must be set before the HIP context exists, i.e. before torch touches the device).  Same-box A/B of
+        # the driver's 20-step window, six interleaved pairs: 22.8 against 23.9 us per step, and the steady step period 19.9 against
+        # 21.5 (profiles/r6_spin_ab.txt) — a yielding wait wakes up late and the launch trains run dry behind it.
+        import ctypes
+        try:
+            rc = ctypes.CDLL('libamdhip64.so').hipSetDeviceFlags(ctypes.c_uint(0x1))
+            host_wait = 'spin' if rc == 0 else f'auto (hipSetDeviceFlags -> {rc})'
+        except OSError as exc:
+            host_wait = f'auto ({exc})'
     import torch
     if args.single_device:
         assert args.backend == 'gloo', '--single-device needs --backend gloo (RCCL wants one GPU per rank)'
@@ -1390,7 +1404,7 @@ def main():
                        'phase': args.phase,
                        'pipeline': ('2 half-batch launches per step on 2 streams (evc_set_pipeline): all outputs of every step written, '
                                     'the halves\' launches overlap across steps' if w.pipeline == 2 else '1 launch per step'),
-                       'launches_per_step': 2 if w.pipeline == 2 else 1, 'settle_steps': args.settle_steps,
+                       'launches_per_step': 2 if w.pipeline == 2 else 1, 'settle_steps': args.settle_steps, 'host_wait': host_wait,
                        'pipelined_steps_timed': int(pipelined_timed)},
             # proof that `world` ranks stepped: gathered over the process group
             'ranks_seen': int(per_rank.shape[0]),
