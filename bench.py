@@ -73,7 +73,7 @@ def headline_line(full: dict, full_path: str | None) -> dict:
     line = _pick(full, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling'))
     line['vs_baseline'] = full.get('vs_baseline')
     line.update(_pick(full, ('dtype', 'data')))
-    line['config'] = _pick(cfg, ('workload', 'envs_per_gpu', 'global_envs', 'parallelism', 'launches_per_step'))
+    line['config'] = _pick(cfg, ('workload', 'envs_per_gpu', 'global_envs', 'parallelism', 'launches_per_step', 'settle_steps', 'host_wait'))
     line.update(_pick(full, ('ranks_seen', 'env_steps_timed')))
     if full.get('n_gpus', 1) > 1:
         line['per_rank_value'] = (full.get('per_rank') or {}).get('value')
