@@ -262,11 +262,20 @@ def test_checkpoint_roundtrip(caltech):
         eng.step(a)
     snap = eng.get_state()
     first = [{k: v.copy() for k, v in eng.step(a).items()} for a in acts[40:]]
+    assert 'entry_rank' in snap and snap['entry_rank'].shape == (N, n) and (snap['entry_rank'] >= -1).all()
+    assert np.array_equal(snap['entry_rank'] >= 0, snap['departure'] != -1)          # a rank wherever an EV is plugged in
     eng.set_state(snap)
     for a, ref in zip(acts[40:], first):
         out = eng.step(a)
         for key in ref:
             assert np.array_equal(out[key], ref[key]), key
+    # a checkpoint WITHOUT the entry order (older ones, hand-made states) rebuilds the lists in station order: the delivered amps of
+    # env.py:445 are then summed in another order — every integer output equal, rewards to the last bits (evcharge.h, ABI 7)
+    eng.set_state({k: v for k, v in snap.items() if k != 'entry_rank'})
+    for a, ref in zip(acts[40:], first):
+        out = eng.step(a)
+        assert np.array_equal(out['terminated'], ref['terminated']) and np.array_equal(out['obs'], ref['obs'])
+        np.testing.assert_allclose(out['reward'], ref['reward'], rtol=1e-12, atol=1e-15)
     eng.close()
 
 
