@@ -185,8 +185,9 @@ def parse_args(argv=None):
                    help='untimed steps at the end of the set-up, in front of the --warmup steps: SURVEY 8(d) defines the metric in steady '
                         'state "excluding one warm-up episode", and with a short --warmup (the driver: 5) the timed window would otherwise '
                         "begin on a GPU that has idled through the set-up's host work (clocks down).  Default: one episode")
-    p.add_argument('--host-wait', default='spin', choices=['spin', 'auto'],
-                   help="how the rank's host thread waits in torch.cuda.synchronize(): 'spin' (default: hipDeviceScheduleSpin) or the runtime's choice")
+    p.add_argument('--host-wait', default='auto', choices=['spin', 'auto'],
+                   help="how the rank's host thread waits in torch.cuda.synchronize(): the runtime's choice (default) or 'spin' "
+                        '(hipDeviceScheduleSpin; measured: no difference, profiles/r6_spin_ab2.txt)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-secondary', action='store_true', help='skip the secondary records (GMM days, multi-agent, battery)')
     p.add_argument('--leg-budget-s', type=float, default=60.0, help='time box of one secondary record')
@@ -1224,19 +1225,23 @@ def main():
     if must_spawn:
         sys.exit(spawn_ranks(args.gpus))
 
+    import torch
     host_wait = 'auto'
     if args.host_wait == 'spin' and os.environ.get('BENCH_SPIN_WAIT', '1') != '0':
-        # The host thread of a rank has nothing to do but wait at the barriers: let its synchronisations SPIN instead of yielding
-        # (hipDeviceScheduleSpin; must be set before the HIP context exists, i.e. before torch touches the device).  Same-box A/B of
-        # the driver's 20-step window, six interleaved pairs: 22.8 against 23.9 us per step, and the steady step period 19.9 against
-        # 21.5 (profiles/r6_spin_ab.txt) — a yielding wait wakes up late and the launch trains run dry behind it.
+        # Measurement switch: the rank's host thread SPINS at its synchronisations (hipDeviceScheduleSpin on the rank's own device; set
+        # before torch touches the device, through the very runtime library torch has loaded — its bundled copy where there is one: a
+        # second copy of the HIP runtime in the process must not happen).  A first A/B seemed to gain 1.1 us per step of the driver's
+        # window (profiles/r6_spin_ab.txt) — but that arm had dlopen'ed the SYSTEM libamdhip64 (ROCm 7.2) before torch, so torch ran on it
+        # instead of its bundled 7.0 copy: the runtime, not the wait mode.  On one runtime the two modes are level (r6_spin_ab2.txt).
         import ctypes
         try:
-            rc = ctypes.CDLL('libamdhip64.so').hipSetDeviceFlags(ctypes.c_uint(0x1))
+            bundled = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+            hip = ctypes.CDLL(bundled if os.path.exists(bundled) else 'libamdhip64.so')
+            dev_index = 0 if args.single_device else local_rank
+            rc = hip.hipSetDevice(ctypes.c_int(dev_index)) or hip.hipSetDeviceFlags(ctypes.c_uint(0x1))
             host_wait = 'spin' if rc == 0 else f'auto (hipSetDeviceFlags -> {rc})'
         except OSError as exc:
             host_wait = f'auto ({exc})'
-    import torch
     if args.single_device:
         assert args.backend == 'gloo', '--single-device needs --backend gloo (RCCL wants one GPU per rank)'
         local_rank = 0
