@@ -1,0 +1,9 @@
+# -mllvm -disable-machine-licm for the engine translation unit against the regular build (GPU box)
+V=$PWD/sustaingym_amd/variants/lib_nolicm.so
+REPS=5 bash tools/r6_ab.sh nolicm | tail -2
+for lib in base nolicm; do
+  if [ $lib = nolicm ]; then export SUSTAINGYM_AMD_LIB=$V; else unset SUSTAINGYM_AMD_LIB; fi
+  echo "== $lib: no projection"; for i in 1 2 3; do python bench.py --no-project --no-secondary --no-cpu-baseline --full-out '' 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['ms_per_step'], r['roofline']['single_launch']['ms_per_step'])"; done
+  echo "== $lib: gmm days"; python tools/gmm_days.py 2>/dev/null | cut -c1-400
+  echo "== $lib: SQ"; tools/pmc_sq.sh 2>/dev/null | tail -1 | cut -c1-330
+done
