@@ -29,6 +29,12 @@
 #include "evc_quad.h"
 #include "evc_solver.h"
 
+#if defined(EVC_TIMELINE) && EVC_TIMELINE == 3   /* measurement builds: twelve stamps inside a wavefront's SECOND quad (slots 2 .. 13) */
+#define EVC_TLP(k) do { if (tl_it == 1) tl_stamp(2 + (k)); } while (0)
+#else
+#define EVC_TLP(k) do { } while (0)
+#endif
+
 namespace evc {
 
 constexpr int kImgFloats = 128;          // observation image of one environment: [demands n | est_departures n], 2 n <= 128 floats
@@ -267,7 +273,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         const unsigned ebase = env * n;
         const unsigned obase = env * F;                     // observation row
         const QuadRaw cur = nxt;
-#ifdef EVC_TIMELINE
+        EVC_TLP(0);
+#if defined(EVC_TIMELINE) && EVC_TIMELINE < 3
         tl_stamp(2 + 2 * tl_it);
 #if EVC_TIMELINE >= 2       /* how long until everything outstanding (prefetched rows, the previous quad's stores) is in */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             rem[c] = buf_ld_f64(r_rem, e < A ? (ebase + e) * 8u : kOob);
         }
 
+        EVC_TLP(1);
         // ---- entries: decode, action, y (box clip of the projection), class sums ----
         bool valid[kSlots];
         unsigned st[kSlots];
@@ -389,6 +397,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 #pragma unroll
         for (int c = 0; c < NS; c++) decode(c);
 
+        EVC_TLP(2);
         // ---- projection screen (PROJECT) ----
         bool pilots_screened = false;
         if (PROJECT) {
@@ -470,6 +479,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             }
         }
 
+        EVC_TLP(3);
         // ---- pilots (env.py:366-378), battery charge ----
         double pilot[kSlots], amps[kSlots];
 #pragma unroll
@@ -512,6 +522,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             }
         }
 
+        EVC_TLP(4);
         // ---- constraint excess of the pilots (env.py:449-452) ----
         // With the projection the y-screen above usually proves the pilots feasible as well
         // (pilots_screened); their class sums are only formed for wavefronts where some row is open.
@@ -536,6 +547,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             }
         }
 
+        EVC_TLP(5);
         // ---- acnsim event pass at iteration t1: unplug (precedence 0) before plug-in (10) ----
         // survivors keep their relative order; pos = index of the entry in the packed list
         bool alive[kSlots];
@@ -642,10 +654,16 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
 #if defined(EVC_TIMELINE) && EVC_TIMELINE < 2
         tl_stamp(3 + 2 * tl_it);
 #endif
+        EVC_TLP(6);
 #ifndef EVC_PREFETCH_EARLY
         quad_next = take_quad();
+#ifdef EVC_ISSUE_ALWAYS      /* measurement builds: behind the last quad five out-of-range loads instead of a merge with the old rows (level) */
+        nxt = issue(quad_next);
+#else
         if (quad_next >= 0) nxt = issue(quad_next);
 #endif
+#endif
+        EVC_TLP(7);
         // ---- observation image: demands / est_departures of the surviving entries ----
         auto scatter_obs = [&](int c) {
             if (live && alive[c]) {
@@ -666,6 +684,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         }
         const double total_rate = row_allreduce_f64(amps_sum);           // env.py:445
 
+        EVC_TLP(8);
         // ---- reward (env.py:431-464) ----
         const double profit = Consts::PROFIT_FACTOR * total_rate;
         const double carbon = Consts::CARBON_COST_FACTOR * total_rate * moer_now;
@@ -696,6 +715,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             if (t_rem & 1u) buf_st_u32(r, (w && q == t_full) ? tb + (t_rem & 2u) * 4u : kOob, (t_rem & 2u) ? mo.z : mo.x);
         };
 
+        EVC_TLP(9);
         // ---- autoreset (gymnasium VectorEnv): terminal observation, then next episode's state ----
         const bool do_reset = done && P.autoreset;
         if (done) episodes += 1;
@@ -723,6 +743,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             if (do_reset) mo = v;
         }
 
+        EVC_TLP(10);
         // ---- observation (env.py:381-394) + state write-back ----
         store_obs(r_obs, live);
         auto store_entry = [&](int c) {
@@ -755,6 +776,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         } else {
             body(std::integral_constant<int, 1>{});
         }
+        EVC_TLP(11);
         lds_sync();
         quad = quad_next;
 #ifdef EVC_TIMELINE

@@ -38,6 +38,15 @@ def main():
     print('percentiles              1     10     50     90     99    100')
     print('entry (us after first) ', q(us[:, 0]))
     print('prologue (0 -> 1)      ', q(us[:, 1] - us[:, 0]))
+    if os.environ.get('EVC_TIMELINE_MODE') == '3':       # -DEVC_TIMELINE=3: slots 2 .. 13 are twelve points inside the wavefront's second quad
+        names = ['top -> entries', 'entries (decode, action image, class sums)', 'screen', 'pilots, charge', 'excess', 'event pass',
+                 'take quad + issue next rows', 'obs image', 'reward', 'autoreset', 'obs + write-back']
+        have = ok[ok] & (us[:, 13] > us[:, 2]) & (us[:, 2] > us[:, 1])
+        print(f'second quad: n={have.sum()}; whole iteration', q((us[:, 13] - us[:, 2])[have]))
+        for k, nm in enumerate(names):
+            print(f'  {nm:<44}', q((us[:, 3 + k] - us[:, 2 + k])[have]), f' mean {np.mean((us[:, 3 + k] - us[:, 2 + k])[have]):.3f}')
+        w.close()
+        return
     for i in range(6):
         a, b = us[:, 2 + 2 * i], us[:, 3 + 2 * i]
         have = (b >= a) & (a >= us[:, 1] - 1e-9) & (b <= us[:, 15] + 1e-9)
