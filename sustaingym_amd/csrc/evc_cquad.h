@@ -733,6 +733,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
                 const int first_arrival = (int)P.sessions[(size_t)next * P.max_sessions].arrival;
                 moer_day = P.slot_moer_day[next];
                 n_sessions = P.n_sessions[next];
+                // (the waits for these three stay in this block, like the one for the table row below)
+                asm volatile("" ::"v"(first_arrival), "v"(moer_day), "v"(n_sessions));
                 next_arrival = n_sessions > 0 ? first_arrival : kNoArrival;
                 count = 0u;
                 d[0] = d[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -740,6 +742,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             // first observation of the next episode: the table's row of period 0 (timestep 0)
             const unsigned mrow0 = (unsigned)moer_day * EVC_MOER_ROWS;
             const v4u v = buf_ld_v4(r_mtail, (do_reset && q < t_chunks) ? (mrow0 * (unsigned)P.mtail_w + st4) * 4u : kOob);
+            // The wait for this load belongs in here.  vmcnt retires in order and a wait is computed for the shortest history any path
+            // has behind the load: left to the first use of `mo` (the observation's stores, behind the join) this load's wait became that
+            // use's wait on EVERY path — vmcnt(1) in the middle of the common path's stores, i.e. every iteration stood until the stores
+            // it had just issued were acknowledged (tools/isa_walk.py; -1.2 % step period, -2 % as one launch, profiles/r6_ab_vmcnt*.txt)
+            asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
             if (do_reset) mo = v;
         }
 
