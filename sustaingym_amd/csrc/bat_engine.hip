@@ -213,7 +213,11 @@ __device__ __forceinline__ void bat_st_f64(bat_rsrc_t r, unsigned off, double x)
 // NT: trajectory rows start on 128-byte lines and are a whole number of lines long (pitch % 32 == 0, aligned base): their stores
 // carry the non-temporal hint (written once, read by somebody else much later): 3.77 -> 3.28 us per step.  Packed 600-byte rows
 // straddle lines and must merge in L2: with nt they lose (3.9 -> 5.4), so they keep the default policy.
-template <int LPE, bool TRAJ, bool NT>
+// KC: the forecast length as a compile-time constant (0: P.k at run time).  The loop is bound by instruction issue, not by memory (a fill
+// kernel writes 6.9 TB/s on this GPU, tools/probes/hbm_rw_mix.py): with a run-time k every float of a row costs range compares
+// against 2k+2, 3k+5, ... and a six-way select for the scalars of the observation; with k = 36 (the reference's forecast horizon,
+// the default) the compiler folds them per unrolled pass — most passes hold no scalar at all.
+template <int LPE, bool TRAJ, bool NT, int KC>
 __global__ __launch_bounds__(256) void bat_rollout_kernel(BatParams P, const float* __restrict__ ring, int ring_len, int steps,
                                                           float* __restrict__ obs, double* __restrict__ reward,
                                                           unsigned char* __restrict__ terminated, float* __restrict__ obs_traj,
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void bat_rollout_kernel(BatParams P, const flo
     const int env_i = (blockIdx.x * 256 + threadIdx.x) / LPE;
     const bool ev = env_i < P.N;                       // rows past N issue the same accesses, all out of range
     const unsigned env = ev ? (unsigned)env_i : 0u;
-    const int k = P.k, F = P.F;
+    const int k = KC > 0 ? KC : P.k, F = KC > 0 ? 4 * KC + 6 : P.F;
     const unsigned N = (unsigned)P.N;
     constexpr int kPairPasses = ((4 * BAT_MAX_FORECAST + 6) / 2 + LPE - 1) / LPE;
     int t = ev ? P.t[env] : BAT_EPISODE_STEPS;
@@ -249,15 +253,23 @@ __global__ __launch_bounds__(256) void bat_rollout_kernel(BatParams P, const flo
         for (int j = 0; j < kPairPasses; j++) {
             const int pr = q + LPE * j;
             a[j] = bat_ld_f32x2(r_ring, (on && pr >= 1 && pr <= k) ? base + 8u * (unsigned)(pr - 1) : kBatOob);
-            float v[2];
+            bool in[2];
+            unsigned idx[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int ii = 2 * pr + h;
                 const bool is_l = ii >= 5 + 2 * k && ii < 5 + 3 * k, is_m = ii >= 6 + 3 * k && ii < 6 + 4 * k;
-                const unsigned idx = is_l ? fc0 + (unsigned)(ii - (5 + 2 * k)) : S * Tk + fc0 + (unsigned)(ii - (6 + 3 * k));
-                v[h] = bat_ld_f32(r_fc, (on && (is_l || is_m)) ? idx * 4u : kBatOob);
+                idx[h] = is_l ? fc0 + (unsigned)(ii - (5 + 2 * k)) : S * Tk + fc0 + (unsigned)(ii - (6 + 3 * k));
+                in[h] = on && (is_l || is_m);
             }
-            f[j] = make_float2(v[0], v[1]);
+            if constexpr (KC > 0) {
+                // one 8-byte load per pair: the two floats of a pair are neighbours in their table, and where only one of them is a
+                // table value (the pairs that also hold lf / mf) the other half reads the neighbouring table entry and is replaced by
+                // the scalar in row_value (buffer loads need 4-byte alignment only)
+                f[j] = bat_ld_f32x2(r_fc, in[0] ? idx[0] * 4u : (in[1] ? (idx[1] - 1u) * 4u : kBatOob));
+            } else {
+                f[j] = make_float2(bat_ld_f32(r_fc, in[0] ? idx[0] * 4u : kBatOob), bat_ld_f32(r_fc, in[1] ? idx[1] * 4u : kBatOob));
+            }
         }
     };
     // everything step i reads, for the environment's period tt; `on` = the step exists and the row is still running
@@ -511,9 +523,14 @@ int bat_rollout_pitched(bat_engine* e, const float* bids_ring_dev, int32_t ring_
     // loops in flight.  BAT_ROLLOUT_LPE=64 selects it (measurements).
     static const int lpe = getenv("BAT_ROLLOUT_LPE") ? atoi(getenv("BAT_ROLLOUT_LPE")) : 16;
     if (lpe != 16 && lpe != 64) return fail(-1, "BAT_ROLLOUT_LPE=%d: 16 or 64", lpe);
-#define BAT_LAUNCH_ROLLOUT(L, T, NTF, GRID)                                                                                    \
-    hipLaunchKernelGGL((bat_rollout_kernel<L, T, NTF>), dim3(GRID), dim3(256), 0, e->stream, e->P, bids_ring_dev, ring_len, steps, obs_dev, \
+#define BAT_LAUNCH_ROLLOUT_(L, T, NTF, KC, GRID)                                                                               \
+    hipLaunchKernelGGL((bat_rollout_kernel<L, T, NTF, KC>), dim3(GRID), dim3(256), 0, e->stream, e->P, bids_ring_dev, ring_len, steps, obs_dev, \
                        reward_dev, terminated_dev, obs_traj_dev, traj_pitch, reward_traj_dev)
+    // (k = 36 compiled in — the default horizon; any other k: the run-time form.  BAT_ROLLOUT_KC=0: measurements)
+    static const bool kc_ok = !(getenv("BAT_ROLLOUT_KC") && atoi(getenv("BAT_ROLLOUT_KC")) == 0);
+    const bool k36 = kc_ok && e->P.k == 36 && e->P.F == 4 * 36 + 6;
+#define BAT_LAUNCH_ROLLOUT(L, T, NTF, GRID)                                                                                    \
+    do { if (k36) BAT_LAUNCH_ROLLOUT_(L, T, NTF, 36, GRID); else BAT_LAUNCH_ROLLOUT_(L, T, NTF, 0, GRID); } while (0)
     const bool traj = obs_traj_dev != nullptr;
     const bool lines = traj && pad_mine && traj_pitch % 32 == 0 && ((uintptr_t)obs_traj_dev & 127u) == 0;
     const int g16 = (e->P.N + 15) / 16, g64 = (e->P.N + 3) / 4;
@@ -527,6 +544,7 @@ int bat_rollout_pitched(bat_engine* e, const float* bids_ring_dev, int32_t ring_
         else BAT_LAUNCH_ROLLOUT(64, true, false, g64);
     }
 #undef BAT_LAUNCH_ROLLOUT
+#undef BAT_LAUNCH_ROLLOUT_
     HIP_TRY(hipGetLastError());
     e->env_steps += (unsigned long long)e->P.N * (unsigned long long)steps;
     return 0;

@@ -92,15 +92,18 @@ def test_battery_lean_stepper_equals_step():
         env.close()
 
 
+@pytest.mark.parametrize('k', [36, 7, 12])
 @pytest.mark.parametrize('trajectory', [True, False])
-def test_battery_rollout_equals_the_loop_of_steps_and_the_oracle(trajectory):
+def test_battery_rollout_equals_the_loop_of_steps_and_the_oracle(trajectory, k):
     """bat_rollout (T steps in one launch, state in registers, bids from a device-resident ring) == T calls of bat_step:
     every observation / reward of the trajectory, the last outputs, the state and the running return — bit for bit — in
-    chunks that start mid-episode and run past its end; and the whole episode against the scalar oracle."""
+    chunks that start mid-episode and run past its end; and the whole episode against the scalar oracle.  k = 36 (the default
+    horizon) runs the kernels with the horizon compiled in and 8-byte forecast loads, any other k the run-time form (odd k: the
+    forecast tables start at the other parity of the row)."""
     import torch
     from oracle.binding import OracleBattery
     from sustaingym_amd.battery import BatteryDispatchVectorEnv, synthetic_market_traces
-    N, k, R = 1000, 36, 7                                      # N not a multiple of 16: a ragged last workgroup
+    N, R = 1000, 7                                             # N not a multiple of 16: a ragged last workgroup
     tr = synthetic_market_traces(64, k, seed=11)
     envs = []
     for _ in range(2):
