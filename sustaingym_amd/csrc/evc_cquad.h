@@ -47,6 +47,9 @@ constexpr int kImgFloats = 128;          // observation image of one environment
 // streaming work is done, the same memory serves as the slow path's SolverLds = {LdsNet net; workspace}
 // (in-kernel queue drain, DRAIN = true).
 constexpr int kDrainListMax = 256;
+// the shape-specialised lean kernels (step_kernel_cquad's NC): stations per packed-word count, and the horizon they assume
+constexpr int kSiteForecast = 36;
+template <int WORDS> struct SiteStations { static constexpr int value = WORDS == 3 ? 54 : (WORDS == 5 ? 52 : 0); };
 struct CquadLds {
     LdsNet net;
     union Images {
@@ -109,8 +112,15 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
 // GREEDY (lean projecting kernels, round 6): the device-resident GreedyAlgorithm compiled in — a run-time flag in the kernel
 // that reads action rows cost the headline 0.5 - 0.7 us per step (measured, profiles/r6_lean_greedy_ab.txt), so the rule has
 // instantiations of its own; the debug kernels keep testing StepIO::action_kind.
-template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES, bool GREEDY = false>
+//
+// NC (lean kernels, round 6): the network's shape as compile-time constants — NC stations, forecast horizon 36, hence the observation
+// width 2 NC + 38 and the MOER tail's 40 floats — for the two sites the reference ships (Caltech 54, JPL 52; the engine picks the
+// instantiation when Params says exactly that, any other shape runs NC = 0 = everything from Params).  Row offsets become shifts and
+// adds instead of 32-bit multiplies, the chunk counts of the observation row and the branches on their remainders fold, compares
+// take inline constants instead of SGPRs: VALU 84.6 -> 79.8, SALU 39.2 -> 34.7 per env-step, -2.7 % step period (profiles/r6_ab_fixn.txt).
+template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES, bool GREEDY = false, int NC = 0>
 __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params P, StepIO io) {
+    static_assert(NC == 0 || !DBG, "the shape-specialised copies exist for the lean kernels");
     static_assert(!GREEDY || (PROJECT && !DBG), "the compiled-in greedy rule exists for the lean projecting kernels");
     static_assert(!DRAIN || (PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");
     __shared__ CquadLds S;
@@ -123,8 +133,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     auto& act_img = S.u.s.act_img;
 
     const unsigned tid = threadIdx.x, lane = tid & 63u, q = lane & 15u, row = lane >> 4, wv = tid >> 6;
-    const unsigned n = (unsigned)P.n, F = (unsigned)P.F;
-    const unsigned m = (unsigned)P.m, k = (unsigned)P.k;
+    const unsigned n = NC ? (unsigned)NC : (unsigned)P.n, k = NC ? (unsigned)kSiteForecast : (unsigned)P.k;
+    const unsigned F = NC ? 2u * n + k + 2u : (unsigned)P.F;
+    const unsigned m = (unsigned)P.m;
     const unsigned N = (unsigned)P.N;
 
     // dense side: lane q owns stations 4q + j, j = 0..3 (action range check, act image, per-station debug outputs)
@@ -135,7 +146,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     // observation row as 16-byte chunks: [demands | est_departures] = 2 n floats = c_full whole chunks (+ a 2-float one if n is
     // odd); tail [forecasted_moer k | prev_moer | timestep] = k + 2 floats = t_full whole chunks + t_rem floats
     const unsigned c_full = (2u * n) >> 2, t_full = (k + 2u) >> 2, t_rem = (k + 2u) & 3u;
-    const unsigned t_chunks = (unsigned)P.mtail_w >> 2;
+    const unsigned mtail_w = NC ? ((k + 2u) + 3u) & ~3u : (unsigned)P.mtail_w;
+    const unsigned t_chunks = mtail_w >> 2;
     const unsigned qrow = q < m ? q : 0u;             // the constraint row this lane screens
 
     const rsrc_t r_win = row_rsrc(P.win_base, P.win_span);      // every engine-owned array (struct Win)
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         if constexpr (kEarly) {
             const unsigned mrow0 = live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) : 0u;
             moer_now0 = buf_ld_f64(r_hist, live ? mrow0 * 8u : kOob);
-            mo0 = buf_ld_v4(r_mtail, (live && q < t_chunks) ? (mrow0 * (unsigned)P.mtail_w + st4) * 4u : kOob);   // chunk q of [forecast | prev | ts]
+            mo0 = buf_ld_v4(r_mtail, (live && q < t_chunks) ? (mrow0 * mtail_w + st4) * 4u : kOob);   // chunk q of [forecast | prev | ts]
             const bool pend0 = live & (next_arrival <= t1) & (cursor < n_sessions);
             const unsigned sidx0 = (unsigned)slot * (unsigned)P.max_sessions + (unsigned)cursor;
             sv0 = buf_ld_v2(r_sess, pend0 ? sidx0 * 8u : kOob);
@@ -571,7 +583,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         if constexpr (!kEarly) {
         const unsigned mrow = live ? ((unsigned)moer_day * EVC_MOER_ROWS + (unsigned)t1) : 0u;
         moer_now = buf_ld_f64(r_hist, live ? mrow * 8u : kOob);
-        mo = buf_ld_v4(r_mtail, (live && q < t_chunks) ? (mrow * (unsigned)P.mtail_w + st4) * 4u : kOob);       // chunk q of [forecast | prev | ts]
+        mo = buf_ld_v4(r_mtail, (live && q < t_chunks) ? (mrow * mtail_w + st4) * 4u : kOob);       // chunk q of [forecast | prev | ts]
         }
 
         if (live) t = t1;
@@ -741,7 +753,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
             }
             // first observation of the next episode: the table's row of period 0 (timestep 0)
             const unsigned mrow0 = (unsigned)moer_day * EVC_MOER_ROWS;
-            const v4u v = buf_ld_v4(r_mtail, (do_reset && q < t_chunks) ? (mrow0 * (unsigned)P.mtail_w + st4) * 4u : kOob);
+            const v4u v = buf_ld_v4(r_mtail, (do_reset && q < t_chunks) ? (mrow0 * mtail_w + st4) * 4u : kOob);
             // The wait for this load belongs in here.  vmcnt retires in order and a wait is computed for the shortest history any path
             // has behind the load: left to the first use of `mo` (the observation's stores, behind the join) this load's wait became that
             // use's wait on EVERY path — vmcnt(1) in the middle of the common path's stores, i.e. every iteration stood until the stores

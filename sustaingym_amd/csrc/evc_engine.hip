@@ -155,6 +155,7 @@ struct evc_engine {
     unsigned long long policy_seed = 0;   // EVC_ACTION_RANDOM (evc_set_policy_seed)
     unsigned env_id_base = 0;
     bool compact = false;        // state layout (Params::compact)
+    bool site_kernels = true;    // lean kernels with the site's shape compiled in where it matches (EVC_SITE_KERNELS=0 at evc_create: never)
     bool use_quad = false;
 };
 
@@ -689,11 +690,18 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
     EVC_LAUNCH_((step_kernel_quad<true, W, true>), (step_kernel_quad<true, W, false>),             \
                 (step_kernel_quad<true, W, false>),                                                \
                 (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, e->quad_grid, W)
+    // the lean kernels with the site's shape compiled in (step_kernel_cquad's NC) where Params describes exactly that shape
+    auto site_shape = [&](int nc) {
+        return nc != 0 && e->site_kernels && e->P.n == nc && e->P.k == kSiteForecast && e->P.F == 2 * nc + kSiteForecast + 2 &&
+               e->P.mtail_w == ((kSiteForecast + 2 + 3) & ~3);
+    };
+#define EVC_CQ_(PROJ, W, DR, WV, GR) (site_shape(SiteStations<W>::value) ? step_kernel_cquad<PROJ, W, false, DR, WV, GR, SiteStations<W>::value> \
+                                                                         : step_kernel_cquad<PROJ, W, false, DR, WV, GR, 0>)
 #define EVC_LAUNCH_CQUAD(W)                                                                         \
     EVC_LAUNCH_((step_kernel_cquad<true, W, true>),                                                                    \
-                (lean_greedy ? step_kernel_cquad<true, W, false, 0, EVC_PROJ_WAVES, true> : step_kernel_cquad<true, W, false, 0, EVC_PROJ_WAVES>), \
-                (lean_greedy ? step_kernel_cquad<true, W, false, 1, EVC_PROJ_WAVES, true> : step_kernel_cquad<true, W, false, 1, EVC_PROJ_WAVES>), \
-                (dbg ? step_kernel_cquad<false, W, true> : step_kernel_cquad<false, W, false>), e->quad_grid, e->proj_grid, W)
+                (lean_greedy ? EVC_CQ_(true, W, 0, EVC_PROJ_WAVES, true) : EVC_CQ_(true, W, 0, EVC_PROJ_WAVES, false)), \
+                (lean_greedy ? EVC_CQ_(true, W, 1, EVC_PROJ_WAVES, true) : EVC_CQ_(true, W, 1, EVC_PROJ_WAVES, false)), \
+                (dbg ? step_kernel_cquad<false, W, true> : EVC_CQ_(false, W, false, EVC_CQUAD_WAVES, false)), e->quad_grid, e->proj_grid, W)
 #define EVC_LAUNCH_WAVE(W)                                                                          \
     EVC_LAUNCH_((step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<true, W>), (step_kernel<false, W>), e->step_grid, e->step_grid, W)
 #define EVC_LAUNCH_ALL(L)                                                                           \
@@ -711,6 +719,7 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
 #undef EVC_LAUNCH_ALL
 #undef EVC_LAUNCH_WAVE
 #undef EVC_LAUNCH_CQUAD
+#undef EVC_CQ_
 #undef EVC_LAUNCH_QUAD
 #undef EVC_LAUNCH_
     if (e->timing) {
@@ -893,6 +902,7 @@ int evc_create(const evc_network_desc* net, int32_t num_envs, int32_t k, uint32_
         const char* lay = getenv("EVC_LAYOUT");          // "dense" | "compact" 
         e->compact = lay ? strcmp(lay, "compact") == 0 : kDefaultCompact;
         P.compact = e->compact ? 1 : 0;
+        if (const char* sk = getenv("EVC_SITE_KERNELS")) e->site_kernels = atoi(sk) != 0;     // measurements / tests (read per engine)
     }
     NetTables T;
     int rc = build_tables(net, P, T);
