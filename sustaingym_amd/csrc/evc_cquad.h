@@ -118,9 +118,14 @@ __device__ __attribute__((noinline)) void drain_local_list(unsigned lds) {
 // instantiation when Params says exactly that, any other shape runs NC = 0 = everything from Params).  Row offsets become shifts and
 // adds instead of 32-bit multiplies, the chunk counts of the observation row and the branches on their remainders fold, compares
 // take inline constants instead of SGPRs: VALU 84.6 -> 79.8, SALU 39.2 -> 34.7 per env-step, -2.7 % step period (profiles/r6_ab_fixn.txt).
-template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES, bool GREEDY = false, int NC = 0>
+// ALIVE (with NC): every environment of every quad exists and none stands behind the end of its episode — the batch is a whole number
+// of quads, autoreset is on (an environment enters a step with t <= 287) and nobody has written other clocks into the scalars (the
+// engine tracks that: evc_set_env_scalars).  `ev`, `live`, `after_done` are constants then, and with them a good part of the
+// predicates folded into buffer offsets: VALU 79.8 -> 72.2, SALU 34.7 -> 30.4 per env-step, -2.5 % step period (profiles/r6_ab_live.txt).
+template <bool PROJECT, int WORDS, bool DBG, bool DRAIN = false, int WAVES = EVC_CQUAD_WAVES, bool GREEDY = false, int NC = 0, bool ALIVE = false>
 __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params P, StepIO io) {
     static_assert(NC == 0 || !DBG, "the shape-specialised copies exist for the lean kernels");
+    static_assert(!ALIVE || NC != 0, "ALIVE comes with a compiled-in shape");
     static_assert(!GREEDY || (PROJECT && !DBG), "the compiled-in greedy rule exists for the lean projecting kernels");
     static_assert(!DRAIN || (PROJECT && !DBG), "the in-kernel drain exists for the lean projecting kernel only");
     __shared__ CquadLds S;
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     auto issue = [&](int quad_) {
         QuadRaw L;
         const unsigned env_ = (unsigned)quad_ * 4u + row;
-        const bool ev_ = quad_ >= 0 && env_ < N;
+        const bool ev_ = quad_ >= 0 && (ALIVE || env_ < N);
         const unsigned eb_ = env_ * n;
         const unsigned soff = ev_ ? env_ * 32u : kOob;
         L.s0 = buf_ld_v4(r_scal, soff);
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
     for (int quad = walk.first < walk.hi ? walk.first : -1; quad >= 0;) {
         int quad_next = -1;                                  // set where the next quad's loads are issued
         const unsigned env = (unsigned)quad * 4u + row;
-        const bool ev = env < N;
+        const bool ev = ALIVE || env < N;
         const unsigned ebase = env * n;
         const unsigned obase = env * F;                     // observation row
         const QuadRaw cur = nxt;
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : WAVES) void step_kernel_cquad(Params
         int t = (int)s0.x, cursor = (int)s0.y, slot = (int)s0.z, moer_day = (int)s0.w;
         int n_sessions = (int)s1.x, next_arrival = (int)s1.y, status = (int)s1.z & kStatusMask, episodes = (int)s1.w;
         const unsigned A = ev ? ((s1.z >> kCountShift) & 0x7fu) : 0u;
-        const bool after_done = ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
+        const bool after_done = !ALIVE && ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
         bool live = ev && !after_done;
         const int t1 = t + 1;
         const bool more = __ballot(A > 16u) != 0ull;            // wave-uniform: entry slots 1..3 in use

@@ -19,12 +19,13 @@ def _engine(net, N, wl, project, debug, k=36):
     return eng
 
 
+@pytest.mark.parametrize('N', [1000, 1001])         # whole quads (the ALIVE copies, with autoreset) / a ragged last quad (the copies that test `env < N`)
 @pytest.mark.parametrize('busy', [False, True])
 @pytest.mark.parametrize('project', [True, False])
 @pytest.mark.parametrize('site', ['caltech', 'jpl'])
-def test_site_kernels_equal_the_general_kernels(site, project, busy, caltech, jpl, monkeypatch):
+def test_site_kernels_equal_the_general_kernels(site, project, busy, N, caltech, jpl, monkeypatch):
     net = caltech if site == 'caltech' else jpl
-    N, n = 1000, net.num_stations                   # not a multiple of 4: a ragged last quad
+    n = net.num_stations
     wl = make_workload(net, N, bank_slots=64, seed=21, busy=busy)
     site_eng = _engine(net, N, wl, project, debug=False)
     monkeypatch.setenv('EVC_SITE_KERNELS', '0')     # read when an engine is created
@@ -62,3 +63,52 @@ def test_other_horizon_takes_the_general_kernel(caltech):
         for key in ('obs', 'reward', 'terminated'):
             assert np.array_equal(g[key], d[key]), (key, t)
     lean.close(); dbg.close()
+
+
+def test_clocks_behind_the_episode_end_leave_the_alive_kernels(caltech):
+    """The ALIVE copies assume no environment stands behind its episode's end; autoreset keeps it so — unless somebody writes
+    such clocks into the scalars (a restored checkpoint of an engine without autoreset, a hand-made state).  The engine notices
+    (evc_set_env_scalars) and runs the copies that test it: rows with t >= 288 report reward 0 / terminated and keep their state,
+    exactly as the debug kernel (general form) has it.  A non-autoreset engine stepping past the end: the same."""
+    N, n = 512, caltech.num_stations
+    wl = make_workload(caltech, N, bank_slots=32, seed=9)
+    lean, dbg = _engine(caltech, N, wl, True, False), _engine(caltech, N, wl, True, True)
+    for e in (lean, dbg):
+        e.reset(host=True)
+    rng = np.random.default_rng(2)
+    acts = rng.random((40, N, n), dtype=np.float32)
+    for t in range(20):
+        g, d = lean.step(acts[t]), dbg.step(acts[t])
+    st = lean.get_state()
+    st['scalars'] = st['scalars'].copy()
+    st['scalars'][::3, 0] = 288                      # every third environment: behind the end
+    st['scalars'][1::7, 0] = 300
+    for e in (lean, dbg):
+        e.set_state(st)
+    for t in range(20, 40):
+        g, d = lean.step(acts[t]), dbg.step(acts[t])
+        for key in ('obs', 'reward', 'terminated'):
+            assert np.array_equal(g[key], d[key]), (key, t)
+        assert (g['reward'][::3] == 0).all() and g['terminated'][::3].all()
+    sc0, sc1 = lean.env_scalars(), dbg.env_scalars()
+    for key in sc0:
+        assert np.array_equal(sc0[key], sc1[key]), key
+    lean.close(); dbg.close()
+    # without autoreset: past the end of the episode
+    from sustaingym_amd.engine import StepEngine
+    engs = []
+    for debug in (False, True):
+        e = StepEngine(caltech, N, moer_forecast_steps=36, project_action=True, autoreset=False, bank_slots=32,
+                       max_sessions=wl['sessions'].shape[1], moer_days=wl['moer'].shape[0], debug_outputs=debug)
+        e.upload_moer(wl['moer']); e.upload_episodes(wl['n_sessions'], wl['sessions'], wl['requested'], wl['moer_day'])
+        e.reset(host=True)
+        engs.append(e)
+    for t in range(292):
+        a = acts[t % 40]
+        g, d = engs[0].step(a), engs[1].step(a)
+        for key in ('obs', 'reward', 'terminated'):
+            assert np.array_equal(g[key], d[key]), (key, t)
+    assert g['terminated'].all() and (g['reward'] == 0).all()
+    for e in engs:
+        e.close()
+
