@@ -47,9 +47,6 @@ constexpr int kImgFloats = 128;          // observation image of one environment
 // streaming work is done, the same memory serves as the slow path's SolverLds = {LdsNet net; workspace}
 // (in-kernel queue drain, DRAIN = true).
 constexpr int kDrainListMax = 256;
-// the shape-specialised lean kernels (step_kernel_cquad's NC): stations per packed-word count, and the horizon they assume
-constexpr int kSiteForecast = 36;
-template <int WORDS> struct SiteStations { static constexpr int value = WORDS == 3 ? 54 : (WORDS == 5 ? 52 : 0); };
 struct CquadLds {
     LdsNet net;
     union Images {

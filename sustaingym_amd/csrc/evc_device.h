@@ -14,6 +14,12 @@
 
 namespace evc {
 
+// The kernels with a site's shape compiled in (step_kernel_cquad's / rollout_kernel's NC): stations per packed-word count of the two
+// networks the reference ships (Caltech: 54 stations, three packed words; JPL: 52, five), and the forecast horizon they assume.
+constexpr int kSiteForecast = 36;
+template <int WORDS> struct SiteStations { static constexpr int value = WORDS == 3 ? 54 : (WORDS == 5 ? 52 : 0); };
+
+
 // ---- constants of the reference (sustaingym/envs/evcharging/env.py:99-114), evaluated in the
 // same expression order as the Python source so that they carry the same float64 values ----
 struct Consts {

@@ -388,6 +388,17 @@ void build_cq_blob(const Params& P, const NetTables& T, CqBlob& B) {
     B.count = cnt;
 }
 
+// Params describes exactly the shape the site kernels have compiled in (step_kernel_cquad's / rollout_kernel's NC)
+bool site_shape_ok(const evc_engine* e, int nc) {
+    return nc != 0 && e->site_kernels && e->P.n == nc && e->P.k == kSiteForecast && e->P.F == 2 * nc + kSiteForecast + 2 &&
+           e->P.mtail_w == ((kSiteForecast + 2 + 3) & ~3);
+}
+// every environment is known to be inside its episode (ALIVE): whole quads, autoreset, clocks in range
+bool all_alive_ok(const evc_engine* e) {
+    static const bool off = getenv("EVC_ALIVE_KERNELS") && atoi(getenv("EVC_ALIVE_KERNELS")) == 0;     // measurements
+    return !off && e->P.N % 4 == 0 && e->P.autoreset != 0 && e->clocks_in_range;
+}
+
 void compute_grids(evc_engine* e) {
     int blocks = (e->P.N + 3) / 4;
     int cap = 4096;
@@ -693,12 +704,9 @@ int launch_step(evc_engine* e, const void* actions_dev, int action_kind, int bin
                 (step_kernel_quad<true, W, false>),                                                \
                 (dbg ? step_kernel_quad<false, W, true> : step_kernel_quad<false, W, false>), e->quad_grid, e->quad_grid, W)
     // the lean kernels with the site's shape compiled in (step_kernel_cquad's NC) where Params describes exactly that shape
-    auto site_shape = [&](int nc) {
-        return nc != 0 && e->site_kernels && e->P.n == nc && e->P.k == kSiteForecast && e->P.F == 2 * nc + kSiteForecast + 2 &&
-               e->P.mtail_w == ((kSiteForecast + 2 + 3) & ~3);
-    };
+    auto site_shape = [&](int nc) { return site_shape_ok(e, nc); };
     // ... and with every environment known to be inside its episode (ALIVE): whole quads, autoreset, clocks in range
-    const bool all_alive = e->P.N % 4 == 0 && e->P.autoreset != 0 && e->clocks_in_range && !(getenv("EVC_ALIVE_KERNELS") && atoi(getenv("EVC_ALIVE_KERNELS")) == 0);
+    const bool all_alive = all_alive_ok(e);
     // (the greedy rule's copies keep the general form: they serve GMM days under policy='greedy', 58 - 69 us per step)
 #define EVC_CQ_(PROJ, W, DR, WV, GR)                                                                                                   \
     ((!(GR) && site_shape(SiteStations<W>::value))                                                                                     \
@@ -826,7 +834,9 @@ int launch_rollout(evc_engine* e, const void* actions_dev, int ring_len, int act
             io.quad_order = e->d_roll_order;
         }
     }
-    if (!launch_rollout_kernel(e->P, io, pgrid, e->stream, ev0, ev1, waves))
+    const int words = (e->P.G + 1) / 2;
+    const bool site_alive = all_alive_ok(e) && site_shape_ok(e, words == 3 ? SiteStations<3>::value : (words == 5 ? SiteStations<5>::value : 0));
+    if (!launch_rollout_kernel(e->P, io, pgrid, e->stream, ev0, ev1, waves, site_alive))
         return fail(EVC_EINVAL, "unsupported class count %d", e->P.G);
     e->last_rollout_waves = waves;
     if (e->timing) {

@@ -157,8 +157,13 @@ __device__ __attribute__((noinline)) void rollout_solve_rows(unsigned lds, unsig
 // traffic is what the wavefronts wait for (SQ_WAIT_ANY 327 of 650 wave cycles): 2 (256 VGPRs, ~90 spilled) runs those 2.40
 // against 1.95e9.  JPL's GMM days prefer 3 again (2.36 against 2.16e9).  The engine therefore MEASURES (evc_engine.hip,
 // launch_rollout): the projecting kernels exist at both settings and the faster one on the caller's own workload is kept.
-template <bool PROJECT, int WORDS, int KIND, int WAVES = EVC_ROLLOUT_WAVES>
+// NC / ALIVE: as step_kernel_cquad's (evc_cquad.h) — the site's shape compiled in, and every environment known to be inside its
+// episode (whole quads, autoreset, clocks in range): the engine launches these copies when both hold, the general form otherwise.
+// Per period the predicates `ev` / `live` / `after_done` fold: synthetic greedy 13.4 -> 11.2 us per period, GMM greedy 28.9 -> 25.7
+// (profiles/r6_rollassume_ab.txt).
+template <bool PROJECT, int WORDS, int KIND, int WAVES = EVC_ROLLOUT_WAVES, int NC = 0, bool ALIVE = false>
 __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO io) {
+    static_assert(!ALIVE || NC != 0, "ALIVE comes with a compiled-in shape");
     __shared__ RolloutLds S;
     LdsNet& net = S.net;
     auto& st_mulw = S.st_mulw;
@@ -167,8 +172,9 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
 
     const unsigned tid = threadIdx.x, lane = tid & 63u, q = lane & 15u, row = lane >> 4;
     const unsigned wv = (unsigned)rfl((int)(tid >> 6));
-    const unsigned n = (unsigned)P.n, F = (unsigned)P.F;
-    const unsigned m = (unsigned)P.m, k = (unsigned)P.k;
+    const unsigned n = NC ? (unsigned)NC : (unsigned)P.n, k = NC ? (unsigned)kSiteForecast : (unsigned)P.k;
+    const unsigned F = NC ? 2u * n + k + 2u : (unsigned)P.F;
+    const unsigned m = (unsigned)P.m;
     const unsigned N = (unsigned)P.N;
 
     // ---- workgroup prologue: network tables, per-station multipliers, clean images ----
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     const unsigned env = quad * 4u + row;
-    const bool ev = env < N;
+    const bool ev = ALIVE || env < N;
     const unsigned ebase = env * n;
 
     const rsrc_t r_win = row_rsrc(P.win_base, P.win_span);
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256, WAVES) void rollout_kernel(Params P, RolloutIO
     unsigned long long ms_passes = 0ull;
 #endif
     for (int step = 0; step < io.steps; step++) {
-        const bool after_done = ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
+        const bool after_done = !ALIVE && ev && t >= EVC_EPISODE_STEPS;   // step() after termination w/o autoreset
         const bool live = ev && !after_done;
         if (after_done) { status |= EVC_STATUS_STEP_AFTER_DONE; reward = 0.0; done_last = true; }
         if (__ballot(live) == 0ull) break;                        // every later step of this quad is the same no-op

@@ -40,17 +40,21 @@ void launch_rollout_order(const Params& P, unsigned* order, hipStream_t stream) 
 }
 
 bool launch_rollout_kernel(const Params& P, const RolloutIO& io, int grid, hipStream_t stream, hipEvent_t start, hipEvent_t stop,
-                           int waves) {
+                           int waves, bool site_alive) {
     const int words = (P.G + 1) / 2;
     const int kind = io.policy == EVC_ACTION_GREEDY ? 0 : (io.policy == EVC_ACTION_RANDOM ? 1 : 2);
     auto launch = [&](auto kernel) {
         if (start && stop) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, stream, start, stop, 0, P, io);
         else hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, stream, P, io);
     };
+#define EVC_ROLL_K(PROJ, W, KD, WV)                                                                 \
+        launch((site_alive && SiteStations<W>::value != 0 && P.n == SiteStations<W>::value)         \
+                   ? rollout_kernel<PROJ, W, KD, WV, SiteStations<W>::value, SiteStations<W>::value != 0> \
+                   : rollout_kernel<PROJ, W, KD, WV, 0, false>)
 #define EVC_ROLL_P(PROJ, W, WV)                                                                     \
-        if (kind == 0) launch(rollout_kernel<PROJ, W, 0, WV>);                                      \
-        else if (kind == 1) launch(rollout_kernel<PROJ, W, 1, WV>);                                 \
-        else launch(rollout_kernel<PROJ, W, 2, WV>);
+        if (kind == 0) EVC_ROLL_K(PROJ, W, 0, WV);                                                  \
+        else if (kind == 1) EVC_ROLL_K(PROJ, W, 1, WV);                                             \
+        else EVC_ROLL_K(PROJ, W, 2, WV);
 #define EVC_ROLL(W)                                                                                 \
     case W:                                                                                         \
         if (P.project && waves == 2) { EVC_ROLL_P(true, W, 2) }                                     \
@@ -62,6 +66,7 @@ bool launch_rollout_kernel(const Params& P, const RolloutIO& io, int grid, hipSt
         default: return false;
     }
 #undef EVC_ROLL_P
+#undef EVC_ROLL_K
 #undef EVC_ROLL
 }
 

@@ -35,7 +35,9 @@ void launch_rollout_order(const Params& P, unsigned* order, hipStream_t stream);
 // Launches rollout_kernel<P.project, (P.G + 1) / 2, policy kind (0 greedy, 1 random, 2 replay)> on `stream`; with start / stop events
 // the launch carries them (hipExtLaunchKernel: the dispatch's own begin / end timestamps).  waves = 2 | 3: the register
 // budget of the projecting kernels (wavefronts per SIMD; rollout_kernel's WAVES).  false: unsupported class count.
+// site_alive: the copies with the site's shape compiled in and every environment inside its episode (rollout_kernel's NC / ALIVE;
+// the caller has checked that Params describes that shape, that the batch is whole quads, autoreset on, clocks in range).
 bool launch_rollout_kernel(const Params& P, const RolloutIO& io, int grid, hipStream_t stream, hipEvent_t start, hipEvent_t stop,
-                           int waves = 3);
+                           int waves = 3, bool site_alive = false);
 
 }  // namespace evc

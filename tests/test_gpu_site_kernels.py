@@ -112,3 +112,36 @@ def test_clocks_behind_the_episode_end_leave_the_alive_kernels(caltech):
     for e in engs:
         e.close()
 
+
+@pytest.mark.parametrize('policy', ['greedy', 'random', 'ring'])
+@pytest.mark.parametrize('site', ['caltech', 'jpl'])
+def test_fused_rollout_site_kernels_equal_the_general_kernels(site, policy, caltech, jpl, monkeypatch):
+    """evc_rollout's kernels exist with the site's shape and the all-alive predicates compiled in (rollout_kernel's NC / ALIVE) and
+    in the general form: same outputs, returns and state over 300 periods (across the episode boundary), on busy days."""
+    import torch
+    net = caltech if site == 'caltech' else jpl
+    N, n = 1024, net.num_stations
+    wl = make_workload(net, N, bank_slots=64, seed=33, busy=True)
+    fast = _engine(net, N, wl, True, debug=False)
+    monkeypatch.setenv('EVC_SITE_KERNELS', '0')
+    general = _engine(net, N, wl, True, debug=False)
+    monkeypatch.delenv('EVC_SITE_KERNELS')
+    outs = []
+    for e in (fast, general):
+        e.reset(slots=(np.arange(N) * 5) % 64)
+        e.set_policy_seed(77, 0)
+        if policy == 'ring':
+            g = torch.Generator(device='cuda'); g.manual_seed(3)
+            ring = torch.rand((7, N, n), device='cuda', generator=g, dtype=torch.float32)
+            o = e.rollout(actions=ring, steps=300)
+        else:
+            o = e.rollout(policy=policy, steps=300)
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in o.items() if v is not None})
+    for key in ('obs', 'reward', 'terminated', 'returns'):
+        assert torch.equal(outs[0][key], outs[1][key]), key
+    s0, s1 = fast.get_state(), general.get_state()
+    for key in s0:
+        assert np.array_equal(s0[key], s1[key]), key
+    fast.close(); general.close()
+
