@@ -1282,13 +1282,21 @@ def main():
     # (same-box A/B, 10 interleaved runs of the 20-step window: 26.0 against 27.2 us per step pipelined, no difference with one launch per step)
     w.run(args.settle_steps)                     # set-up: one untimed episode (steady state, clocks up); not part of --warmup / --steps
     steps0 = w.eng.read_metrics()['env_steps'] + float(N) * args.warmup
+    # (the interpreter's cyclic garbage collector stays out of the timed steps, as in timeit: a generation-2 pass over this
+    # process's heap takes milliseconds, and the device runs only ~200 us behind the host's launches.  Collected and switched
+    # off BEFORE the warm-up steps: milliseconds of idle GPU between warm-up and timed steps cost the window 1.2 us per step)
+    import gc
+    gc.collect()
+    gc.disable()
     w.run(args.warmup)
     barrier()
     pipelined0 = w.eng.pipelined_steps()           # a host-side counter: no engine work
     t0 = time.perf_counter()
     w.run(args.steps)
+    host_issue_s = time.perf_counter() - t0         # how long the host took to enqueue the timed steps (diagnostic)
     barrier()                    # torch.cuda.synchronize drains the whole device, the side streams of the pipelined mode included
     local_elapsed = time.perf_counter() - t0
+    gc.enable()
     elapsed = max_over_ranks(local_elapsed, coll_dev)
     timed_env_steps = w.eng.read_metrics()['env_steps'] - steps0
     pipelined_timed = w.eng.pipelined_steps() - pipelined0
@@ -1330,6 +1338,7 @@ def main():
         # included); `frac_steady`, `frac_hbm`, `frac_floor`: on the steady step period measured after it with HIP events
         roofline = roofline_record(w, timed, alg_b, window_ms, abar)
         roofline['launch_overhead_ms'] = round(window_ms - roofline.get('step_period_ms', roofline['avg_kernel_ms']), 5)
+        roofline['host_issue_ms_per_step'] = round(host_issue_s / args.steps * 1e3, 5)      # of the timed steps, rank 0
         if w.pipeline == 2 and not args.no_single_launch:
             # the same workload as ONE launch per step (evc_set_pipeline(1)), for continuity with rounds 1-2
             w.eng.set_pipeline(1)
