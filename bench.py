@@ -1281,6 +1281,13 @@ def main():
     # (a metrics kernel + copy there leaves the GPU idle for a few hundred microseconds more)
     # (same-box A/B, 10 interleaved runs of the 20-step window: 26.0 against 27.2 us per step pipelined, no difference with one launch per step)
     w.run(args.settle_steps)                     # set-up: one untimed episode (steady state, clocks up); not part of --warmup / --steps
+    if args.settle_steps > 0:
+        # ... and the host runtime's housekeeping for those hundreds of launches, which it does in the first calls BEHIND the next
+        # synchronisation (tools/probes/host_issue_profile.py: ~20 us per step() call for the first ten instead of 8): absorbed here
+        # by a synchronisation and sixteen untimed steps, not by the first steps of a short timed window
+        barrier()
+        w.run(16)
+        barrier()
     steps0 = w.eng.read_metrics()['env_steps'] + float(N) * args.warmup
     # (the interpreter's cyclic garbage collector stays out of the timed steps, as in timeit: a generation-2 pass over this
     # process's heap takes milliseconds, and the device runs only ~200 us behind the host's launches.  Collected and switched
