@@ -155,6 +155,8 @@ struct evc_engine {
     unsigned long long policy_seed = 0;   // EVC_ACTION_RANDOM (evc_set_policy_seed)
     unsigned env_id_base = 0;
     bool compact = false;        // state layout (Params::compact)
+    int side_streams_replaced = 0;      // evc_set_pipeline(2): second-half streams rejected because they did not run beside the first half's
+    bool side_streams_overlap = true;   // ... and whether the pair in use does
     bool site_kernels = true;    // lean kernels with the site's shape compiled in where it matches (EVC_SITE_KERNELS=0 at evc_create: never)
     bool clocks_in_range = true; // every environment's t is in [0, 288): true for the zeroed state, kept by reset and by stepping under
                                  // autoreset; evc_set_env_scalars re-evaluates it (step_kernel_cquad's ALIVE)
@@ -164,6 +166,13 @@ struct evc_engine {
 namespace {
 
 __global__ void side_stream_warmup_kernel() {}
+
+// ... and reports when it began and ended (evc_set_pipeline: do the two side streams run concurrently?)
+__global__ void spin_stamp_kernel(unsigned long long* out, unsigned ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) { out[0] = t0; out[1] = wall_clock64(); }
+}
 
 // one wavefront that does nothing for `ticks` of the 100 MHz constant clock (launch_split: start skew of the second half)
 __global__ void skew_kernel(unsigned ticks) {
@@ -1082,6 +1091,42 @@ int evc_set_pipeline(evc_engine* e, int32_t halves) {
         for (int h = 0; h < 2; h++) {
             hipLaunchKernelGGL(side_stream_warmup_kernel, dim3(1), dim3(64), 0, e->side[h]);
             HIP_TRY(hipStreamSynchronize(e->side[h]));
+        }
+        // Two HIP streams are not promised to run concurrently, and sometimes they do not: the second engine of a process
+        // regularly gets a pair whose kernels run one after the other (tools/probes/side_overlap.py: two 190 us spin kernels take
+        // 366 us instead of 200) — its pipelined step then takes 31 us instead of 18.  Checked here with two 60 us spin kernels that
+        // report their begin and end; a second-half stream that does not overlap the first is replaced (the rejected ones are kept
+        // until the search ends, so that the runtime hands out other hardware queues), at most eight times.
+        {
+            static const bool check = !(getenv("EVC_SIDE_OVERLAP_CHECK") && atoi(getenv("EVC_SIDE_OVERLAP_CHECK")) == 0);
+            unsigned long long* const stamps = (unsigned long long*)e->d_metrics;          // 8 doubles of scratch (evc_read_metrics zeroes them before use)
+            auto overlaps = [&](bool& ok) -> int {
+                ok = false;
+                for (int rep = 0; rep < 2 && !ok; rep++) {
+                    for (int h = 0; h < 2; h++) hipLaunchKernelGGL(spin_stamp_kernel, dim3(1), dim3(64), 0, e->side[h], stamps + 2 * h, 6000u);
+                    for (int h = 0; h < 2; h++) HIP_TRY(hipStreamSynchronize(e->side[h]));
+                    unsigned long long t[4];
+                    HIP_TRY(hipMemcpy(t, stamps, sizeof(t), hipMemcpyDeviceToHost));
+                    ok = t[2] < t[1] && t[0] < t[3];               // each began before the other ended
+                }
+                return EVC_OK;
+            };
+            std::vector<hipStream_t> rejected;
+            bool ok = true;
+            if (check) {
+                if (int rc = overlaps(ok)) return rc;
+                for (int attempt = 0; !ok && attempt < 8; attempt++) {
+                    rejected.push_back(e->side[1]);
+                    e->side[1] = nullptr;
+                    HIP_TRY(hipStreamCreateWithFlags(&e->side[1], hipStreamNonBlocking));
+                    hipLaunchKernelGGL(side_stream_warmup_kernel, dim3(1), dim3(64), 0, e->side[1]);
+                    HIP_TRY(hipStreamSynchronize(e->side[1]));
+                    if (int rc = overlaps(ok)) return rc;
+                }
+            }
+            for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+            e->side_streams_replaced = (int)rejected.size();
+            e->side_streams_overlap = ok;
         }
         e->side_ready = true;
     }
