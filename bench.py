@@ -93,7 +93,7 @@ def headline_line(full: dict, full_path: str | None) -> dict:
     line['cpu_baseline'] = _pick(cpu, ('value', 'unit', 'cores', 'kind', 'sample', 'single_thread_value')) or None
     sec = full.get('secondary') or {}
     scal = {}
-    for key in ('gmm_caltech', 'gmm_jpl', 'real_caltech'):
+    for key in ('action_ring_32', 'gmm_caltech', 'gmm_jpl', 'real_caltech'):
         if isinstance(sec.get(key), dict) and 'ms_per_step' in sec[key]:
             scal[key + '_us_per_step'] = round(sec[key]['ms_per_step'] * 1e3, 2)
     for key in ('rollout_greedy_65536_gmm', 'rollout_random_65536_gmm'):
@@ -954,6 +954,22 @@ def secondary_tie_snap(dev_index, battery) -> dict:
             'fraction_of_all_pilots': round(met['tie_snap_near_boundary'] / pilots, 10)}
 
 
+def secondary_action_ring(site, dev_index, battery, project, slices=32) -> dict:
+    """The headline workload with an action ring that does NOT fit the 256 MB Infinity Cache: the default ring (8 slices x N x n
+    floats = 113 MB at 65 536 x 54) comes round every eight steps and is served from that cache together with the observations and
+    the state (~180 MB in all); with 32 slices (450 MB) every action row of every step is read from HBM.  A policy that writes its
+    actions on the device each step is the first case; this leg is the second."""
+    w = EvWorkload(site, 65536, dev_index, 0, project=project, battery=battery, ring=slices)
+    w.run(2 * EPISODE)
+    ms = w.wall_ms_per_step(2 * EPISODE)
+    w.eng.set_pipeline(1)
+    w.run(64)
+    single = w.wall_ms_per_step(EPISODE)
+    w.close()
+    return {'workload': f'65536 x {w.n}-station ({site}), as the headline, action ring of {slices} slices ({slices * 65536 * w.n * 4 / 1e6:.0f} MB: every row from HBM)',
+            'ms_per_step': round(ms, 5), 'env_steps_per_s': round(65536 / (ms * 1e-3), 1), 'single_launch_ms_per_step': round(single, 5)}
+
+
 def secondary_sync_reference(site, dev_index, battery, project) -> dict:
     """The headline workload with SYNCHRONISED episode phases (what a freshly reset vector env plays, and what round 1's
     bench timed): the whole-day average, and the 20 steps after 5 warm-up steps of a fresh day — the driver's window,
@@ -1384,6 +1400,7 @@ def main():
         secondary = {}
         legs_deadline = time.monotonic() + args.secondary_budget_s
         for name, fn in (('sync_reference', lambda: secondary_sync_reference(args.site, local_rank, args.battery, project)),
+                         ('action_ring_32', lambda: secondary_action_ring(args.site, local_rank, args.battery, project)),
                          ('gmm_caltech', lambda: secondary_days('caltech', 'gmm', local_rank, args.battery)),
                          ('gmm_jpl', lambda: secondary_days('jpl', 'gmm', local_rank, args.battery)),
                          ('real_caltech', lambda: secondary_days('caltech', 'real', local_rank, args.battery)),
@@ -1421,7 +1438,9 @@ def main():
                                    f'episode phases {"staggered uniformly over the day" if args.phase == "stagger" else "synchronised"}'
                                    + tags,
                        'envs_per_gpu': N, 'global_envs': N * world, 'parallelism': f'env-shard x{world}',
-                       'actions': 'U[0,1) float32 resident in HBM', 'battery_model': args.battery,
+                       'actions': f'U[0,1) float32 resident in HBM, a ring of {args.ring} slices ({args.ring * N * n * 4 / 1e6:.0f} MB) that comes round every {args.ring} steps — '
+                                  'with 8 slices it stays in the 256 MB Infinity Cache between visits (secondary.action_ring_32: every row from HBM)',
+                       'battery_model': args.battery,
                        'phase': args.phase,
                        'pipeline': ('2 half-batch launches per step on 2 streams (evc_set_pipeline): all outputs of every step written, '
                                     'the halves\' launches overlap across steps' if w.pipeline == 2 else '1 launch per step'),
