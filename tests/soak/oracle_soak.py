@@ -1,5 +1,7 @@
 # GPU (lean kernels, projection on) vs the C oracle on device-generated GMM days at scale: counts
-# instead of asserting.  Usage: python tests/soak/oracle_soak.py [site] [N] [seeds]
+# instead of asserting.  Usage: python tests/soak/oracle_soak.py [site] [N] [seeds] [autoreset]
+# autoreset = 1: two days per seed with autoreset over the bank (stride 1) — the kernels with every environment known to be inside its
+# episode (step_kernel_cquad's ALIVE) instead of the copies that test it
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # repo root
 import numpy as np
@@ -11,6 +13,7 @@ from sustaingym_amd.synthetic import synthetic_moer
 site = sys.argv[1] if len(sys.argv) > 1 else 'caltech'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+auto = len(sys.argv) > 4 and int(sys.argv[4]) != 0
 net = site_str_to_site(site); n = net.num_stations
 tabs = gmm_device_tables(site, 'Summer 2019')
 moer = synthetic_moer(tabs['num_days'], seed=3)
@@ -18,18 +21,18 @@ tot = dict(env_steps=0, term=0, est=0, demand_rel_gt_1e6=0, reward_rel_gt_1e9=0,
 worst_r = 0.0
 t0 = time.time()
 for seed in range(seeds):
-    eng = StepEngine(net, N, project_action=True, autoreset=False, bank_slots=N, max_sessions=128, moer_days=tabs['num_days'])
+    eng = StepEngine(net, N, project_action=True, autoreset=auto, bank_slots=N, max_sessions=128, moer_days=tabs['num_days'])
     eng.upload_moer(moer, 0); eng.upload_gmm(tabs); eng.generate_episodes(0, N, 1000 + seed, 77 * seed)
     ns, sess, req, day, mp = eng.download_episodes(0, N)
     ob = OracleBatch(OracleNetwork(net), N, 36, project=True)
-    ob.set_bank(ns, sess, req, day, moer)
+    ob.set_bank(ns, sess, req, day, moer, autoreset_stride=1)
     slots = np.arange(N, dtype=np.int32)
     assert np.array_equal(eng.reset(slots=slots, host=True), ob.reset(slots))
     rng = np.random.default_rng(seed)
-    for t in range(288):
+    for t in range(576 if auto else 288):
         a = rng.random((N, n)).astype(np.float32)
         if t % 40 == 20: a[::5] = 1.0
-        g = eng.step(a); o = ob.step(a, debug=False)
+        g = eng.step(a); o = ob.step(a, debug=False, autoreset=auto)
         tot['env_steps'] += N
         tot['term'] += int((g['terminated'] != o['terminated']).sum())
         tot['est'] += int((g['obs'][:, n:2*n] != o['obs'][:, n:2*n]).sum())
@@ -40,4 +43,4 @@ for seed in range(seeds):
         tot['slow'] += eng.last_slow_count()
     tot['noconv'] += int(((eng.env_scalars()['status'] & 2) != 0).sum())
     eng.close()
-print(site, tot, f'worst relative reward difference {worst_r:.2e}', f'{time.time() - t0:.0f} s')
+print(site, 'autoreset' if auto else '', tot, f'worst relative reward difference {worst_r:.2e}', f'{time.time() - t0:.0f} s')
