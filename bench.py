@@ -445,7 +445,9 @@ def roofline_record(w: EvWorkload, timed: dict, survey_bytes_per_env_step: int, 
            'achieved': round(alg / (window * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': frac(alg, window),
            'traffic': traffic,
            'window': ('achieved / frac / frac_survey: the timed region of ms_per_step' if window_ms is not None
-                      else 'achieved / frac / frac_survey: steady step period') + '; frac_hbm / frac_steady: steady step period (HIP events)',
+                      else 'achieved / frac / frac_survey: steady step period') + '; frac_hbm / frac_steady: steady step period (HIP events)'
+                     + "; frac_survey prices SURVEY's station-shaped 2309 B per env-step, more than this layout moves: it can pass 1"
+                     + '; traffic / frac_hbm are L2 <-> fabric bytes, part of them served by the 256 MB Infinity Cache (config.actions)',
            'frac_steady': frac(alg, avg),
            'frac_survey': frac(survey, window), 'frac_survey_steady': frac(survey, avg),
            'frac_hbm_timed_window': frac(traffic, window) if traffic else None,
